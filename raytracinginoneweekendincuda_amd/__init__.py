@@ -1,0 +1,25 @@
+"""MI355X-native path tracer: host-side mirror of the reference's construction/render API.
+
+The compute path is the hand-written gfx950 HIP library ``librtow_hip.so`` (C-ABI in
+``include/rtow.h``).  There is no CPU fallback: importing works anywhere (so that host-side scene
+logic can be tested), rendering raises unless the HIP library is loaded and a GPU is present.
+"""
+from .api import (  # noqa: F401
+    RtowError,
+    Rng,
+    Scene,
+    Film,
+    RenderParams,
+    RenderStats,
+    builtin_scene,
+    stripe_rows,
+    deinterleave,
+    write_ppm,
+    library_path,
+    lib,
+)
+
+__all__ = [
+    "RtowError", "Rng", "Scene", "Film", "RenderParams", "RenderStats", "builtin_scene",
+    "stripe_rows", "deinterleave", "write_ppm", "library_path", "lib",
+]

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's construction and render interface, over the C-ABI.
+
+Names follow the reference's classes (R/ = reference RayTracinginOneWeekend/): ``Scene.Sphere(center,
+radius, material)`` is ``new Sphere(center, radius, material)`` (R/Sphere.h:12), ``Scene.Lambertian``
+is R/Material.h:57/63, ``Scene.BvhNode(list)`` is ``new BvhNode(list, 0, n, ...)`` (R/BvhNode.h:50) and
+so on; ``Film.render`` is the RenderInit + Render launch pair (R/kernel.cu:675-691) and ``write_ppm`` the
+writer at R/kernel.cu:696-721.  Errors surface as RtowError carrying the library's message.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RenderParams, RenderStats, SceneInfo  # noqa: F401
+
+
+class RtowError(RuntimeError):
+    pass
+
+
+def lib():
+    return _lib.load()
+
+
+def library_path():
+    return _lib.LIB_PATH
+
+
+def _err():
+    return lib().rt_last_error().decode()
+
+
+def _check(status):
+    if status != 0:
+        raise RtowError(f"status {status}: {_err()}")
+
+
+def _h(handle):
+    if not handle:
+        raise RtowError(_err())
+    return handle
+
+
+def _v3(v):
+    return (C.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+class Rng:
+    """curand_init(seed, sequence, 0) + curand_uniform (R/kernel.cu:101-107, RND at :157)."""
+
+    def __init__(self, seed=1984, sequence=0, salt_kind=0):
+        self._p = lib().rt_rng_create_salted(seed, sequence, salt_kind)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().rt_rng_destroy(self._p)
+            self._p = None
+
+    def uniform(self):
+        return lib().rt_rng_uniform(self._p)
+
+    def next_u32(self):
+        return lib().rt_rng_next_u32(self._p)
+
+    def state(self):
+        out = (C.c_uint32 * 6)()
+        lib().rt_rng_state(self._p, out)
+        return list(out)
+
+
+class Scene:
+    def __init__(self):
+        self._p = lib().rt_scene_create()
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().rt_scene_destroy(self._p)
+            self._p = None
+
+    # ---- textures (R/Texture.h) ----
+    def SolidColor(self, c):
+        return _h(lib().rt_solid_color(self._p, *map(float, c)))
+
+    def CheckerTexture(self, scale, even, odd):
+        return _h(lib().rt_checker_texture(self._p, scale, even, odd))
+
+    def ImageTexture(self, rgb):
+        if rgb is None:
+            return _h(lib().rt_image_texture(self._p, None, 0, 0))
+        a = np.ascontiguousarray(rgb, dtype=np.uint8)
+        return _h(lib().rt_image_texture(self._p, a.ctypes.data, a.shape[1], a.shape[0]))
+
+    def NoiseTexture(self, scale, rng):
+        return _h(lib().rt_noise_texture(self._p, scale, rng._p))
+
+    # ---- materials ----
+    def Lambertian(self, c):
+        if isinstance(c, int):
+            return _h(lib().rt_lambertian_tex(self._p, c))
+        return _h(lib().rt_lambertian(self._p, *map(float, c)))
+
+    def Metal(self, c, fuzz):
+        return _h(lib().rt_metal(self._p, float(c[0]), float(c[1]), float(c[2]), fuzz))
+
+    def Dielectric(self, ior):
+        return _h(lib().rt_dielectric(self._p, ior))
+
+    def DiffuseLight(self, c):
+        if isinstance(c, int):
+            return _h(lib().rt_diffuse_light_tex(self._p, c))
+        return _h(lib().rt_diffuse_light(self._p, *map(float, c)))
+
+    def Isotropic(self, c):
+        if isinstance(c, int):
+            return _h(lib().rt_isotropic_tex(self._p, c))
+        return _h(lib().rt_isotropic(self._p, *map(float, c)))
+
+    # ---- hittables ----
+    def Sphere(self, center, radius, material):
+        return _h(lib().rt_sphere(self._p, float(center[0]), float(center[1]), float(center[2]), radius, material))
+
+    def MovingSphere(self, c0, c1, t0, t1, radius, material):
+        return _h(lib().rt_moving_sphere(self._p, *map(float, c0), *map(float, c1), t0, t1, radius, material))
+
+    def Quad(self, q, u, v, material):
+        return _h(lib().rt_quad(self._p, _v3(q), _v3(u), _v3(v), material))
+
+    def Translate(self, obj, offset):
+        return _h(lib().rt_translate(self._p, obj, *map(float, offset)))
+
+    def RotateY(self, obj, degrees):
+        return _h(lib().rt_rotate_y(self._p, obj, degrees))
+
+    def MakeBox(self, a, b, material):
+        return _h(lib().rt_make_box(self._p, _v3(a), _v3(b), material))
+
+    def HittableList(self, items):
+        arr = (C.c_uint32 * max(1, len(items)))(*items)
+        return _h(lib().rt_hittable_list(self._p, arr, len(items)))
+
+    def ConstantMedium(self, boundary, density, c):
+        if isinstance(c, int):
+            return _h(lib().rt_constant_medium_tex(self._p, boundary, density, c))
+        return _h(lib().rt_constant_medium(self._p, boundary, density, *map(float, c)))
+
+    def BvhNode(self, items):
+        """Sorts ``items`` in place like the reference sorts list[] (R/BvhNode.h:180-193)."""
+        arr = (C.c_uint32 * max(1, len(items)))(*items)
+        root = _h(lib().rt_bvh_node(self._p, arr, len(items)))
+        items[:] = list(arr)[: len(items)]
+        return root
+
+    def BoundingBox(self, obj):
+        out = (C.c_double * 6)()
+        _check(lib().rt_hittable_bounding_box(self._p, obj, out))
+        return list(out)
+
+    # ---- world / camera / commit ----
+    def SetWorld(self, world):
+        _check(lib().rt_scene_set_world(self._p, world))
+
+    def Camera(self, lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist, time0=0.0, time1=0.0,
+               background=(0.70, 0.80, 1.00)):
+        _check(lib().rt_scene_set_camera(self._p, _v3(lookfrom), _v3(lookat), _v3(vup), vfov, aspect, aperture,
+                                         focus_dist, time0, time1, _v3(background)))
+
+    def Commit(self):
+        _check(lib().rt_scene_commit(self._p))
+
+    def build_builtin(self, scene_id, world_kind, width, height, seed=1984, earth=None):
+        if earth is not None:
+            earth = np.ascontiguousarray(earth, dtype=np.uint8)
+            self._keep.append(earth)
+            _check(lib().rt_scene_build_builtin(self._p, scene_id, world_kind, width, height, seed, earth.ctypes.data,
+                                                earth.shape[1], earth.shape[0]))
+        else:
+            _check(lib().rt_scene_build_builtin(self._p, scene_id, world_kind, width, height, seed, None, 0, 0))
+        return self
+
+    # ---- introspection ----
+    def info(self):
+        out = SceneInfo()
+        _check(lib().rt_scene_get_info(self._p, C.byref(out)))
+        return {n: getattr(out, n) for n, _ in SceneInfo._fields_ if n != "reserved"}
+
+    def dump_leaves(self):
+        n = lib().rt_scene_dump_leaves(self._p, 0, None, None)
+        if n < 0:
+            raise RtowError(_err())
+        kinds = np.zeros(max(n, 1), dtype=np.int32)
+        boxes = np.zeros((max(n, 1), 6), dtype=np.float64)
+        lib().rt_scene_dump_leaves(self._p, n, kinds.ctypes.data_as(C.POINTER(C.c_int)), boxes.ctypes.data_as(_lib.D3))
+        return kinds[:n], boxes[:n]
+
+    def dump_nodes(self):
+        n = lib().rt_scene_dump_nodes(self._p, 0, None, None)
+        if n < 0:
+            raise RtowError(_err())
+        boxes = np.zeros((max(n, 1), 6), dtype=np.float64)
+        abe = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        lib().rt_scene_dump_nodes(self._p, n, boxes.ctypes.data_as(_lib.D3), abe.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return boxes[:n], abe[:n]
+
+    def dump_camera(self):
+        out = np.zeros(27, dtype=np.float64)
+        _check(lib().rt_scene_dump_camera(self._p, out.ctypes.data_as(_lib.D3)))
+        return out
+
+    def upload(self, device=0):
+        _check(lib().rt_scene_upload(self._p, device))
+
+    # ---- one-call render on one GPU ----
+    def render(self, width, height, spp, max_depth=50, seed=1984, variant=0, device=0):
+        p = RenderParams(width, height, spp, max_depth, seed, 8, 0, 1, variant, device, 0, None)
+        frame = np.zeros((height, width, 3), dtype=np.float64)
+        st = RenderStats()
+        _check(lib().rt_render(self._p, C.byref(p), frame.ctypes.data_as(_lib.D3), C.byref(st)))
+        return frame, st
+
+
+def builtin_scene(scene_id, world_kind, width, height, seed=1984, earth=None):
+    """CreateWorld(sceneId) (R/kernel.cu:176-543); world_kind 0 = BvhNode world, 1 = HittableList world."""
+    return Scene().build_builtin(scene_id, world_kind, width, height, seed, earth)
+
+
+class Film:
+    """frameBuffer + randState of one GPU (R/kernel.cu:606-613), restricted to this rank's row stripes."""
+
+    def __init__(self, width, height, device=0, stripe_rows=8, rank=0, world_size=1):
+        self.width, self.height, self.device = width, height, device
+        self.stripe_rows, self.rank, self.world_size = stripe_rows, rank, world_size
+        self._p = lib().rt_film_create(device, width, height, stripe_rows, rank, world_size)
+        if not self._p:
+            raise RtowError(_err())
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().rt_film_destroy(self._p)
+            self._p = None
+
+    def params(self, spp, max_depth=50, seed=1984, variant=0, flags=0, stream=None):
+        return RenderParams(self.width, self.height, spp, max_depth, seed, self.stripe_rows, self.rank, self.world_size,
+                            variant, self.device, flags, stream)
+
+    def launch(self, scene, params):
+        _check(lib().rt_render_launch(scene._p, self._p, C.byref(params)))
+
+    def finish(self, scene):
+        st = RenderStats()
+        _check(lib().rt_render_finish(scene._p, self._p, C.byref(st)))
+        return st
+
+    def render(self, scene, spp, **kw):
+        self.launch(scene, self.params(spp, **kw))
+        return self.finish(scene)
+
+    def device_pixels(self):
+        return lib().rt_film_device_pixels(self._p), lib().rt_film_pixel_bytes(self._p)
+
+    def download(self):
+        frame = np.zeros((self.height, self.width, 3), dtype=np.float64)
+        _check(lib().rt_film_download(self._p, frame.ctypes.data_as(_lib.D3), self.width, self.height))
+        return frame
+
+
+def stripe_rows(height, stripe, rank, world_size):
+    n = lib().rt_stripe_rows(height, stripe, rank, world_size, None, 0)
+    if n < 0:
+        raise RtowError("bad stripe arguments")
+    rows = (C.c_int * max(n, 1))()
+    lib().rt_stripe_rows(height, stripe, rank, world_size, rows, n)
+    return list(rows)[:n]
+
+
+def deinterleave(gathered, width, height, stripe, world_size):
+    """gathered: (world_size, rows_max*width*3) float64, as gathered rank-major over RCCL."""
+    g = np.ascontiguousarray(gathered, dtype=np.float64)
+    frame = np.zeros((height, width, 3), dtype=np.float64)
+    _check(lib().rt_deinterleave(g.ctypes.data_as(_lib.D3), width, height, stripe, world_size, g.shape[1],
+                                 frame.ctypes.data_as(_lib.D3)))
+    return frame
+
+
+def write_ppm(path, frame):
+    f = np.ascontiguousarray(frame, dtype=np.float64)
+    _check(lib().rt_write_ppm(str(path).encode(), f.ctypes.data_as(_lib.D3), f.shape[1], f.shape[0]))

@@ -1,0 +1,336 @@
+// device_scene.cpp -- HIP side of the render API (include/rtow.h): table upload, the film (framebuffer +
+// per-pixel RNG state, the reference's frameBuffer / randState, R/kernel.cu:606-613), launches and
+// timing.  Replaces the host driver section R/kernel.cu:675-691.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rtow.h"
+#include "render_iface.h"
+#include "scene_host.h"
+
+namespace rtow {
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    return fail(RT_ERR_HIP, std::string("HIP error = ") + std::to_string((unsigned)e) + " (" + hipGetErrorString(e) +
+                                ") at '" + what + "'");
+}
+#define HIP_TRY(expr)                                     \
+    do {                                                  \
+        hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+struct DeviceTables {
+    int device = -1;
+    std::vector<void *> allocations;
+    DeviceScene scene{};
+};
+
+void release_device_tables(DeviceTables *t)
+{
+    if (!t) return;
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(t->device);
+    for (void *p : t->allocations) hipFree(p);
+    hipSetDevice(prev);
+    delete t;
+}
+
+template <class T>
+static int upload(DeviceTables &dt, const std::vector<T> &host, const T *&dev)
+{
+    dev = nullptr;
+    // keep every table pointer valid (never null) so that speculative loads stay in bounds
+    size_t bytes = (host.empty() ? 1 : host.size()) * sizeof(T);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    dt.allocations.push_back(p);
+    if (!host.empty())
+        HIP_TRY(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    else
+        HIP_TRY(hipMemset(p, 0, bytes));
+    dev = static_cast<const T *>(p);
+    return RT_OK;
+}
+
+// jump table: one copy per device for the life of the process
+static std::mutex g_jump_mutex;
+static std::map<int, uint32_t *> g_jump_tables;
+static int device_jump_table(int device, const uint32_t **out)
+{
+    std::lock_guard<std::mutex> lock(g_jump_mutex);
+    auto it = g_jump_tables.find(device);
+    if (it == g_jump_tables.end()) {
+        uint32_t *p = nullptr;
+        HIP_TRY(hipMalloc((void **)&p, kJumpTableWords * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(p, host_jump_table(), kJumpTableWords * sizeof(uint32_t), hipMemcpyHostToDevice));
+        it = g_jump_tables.emplace(device, p).first;
+    }
+    *out = it->second;
+    return RT_OK;
+}
+
+static int select_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(RT_ERR_NO_DEVICE, "no HIP device available: the gfx950 render path cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= count) return fail(RT_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return RT_OK;
+}
+
+struct FilmImpl {
+    int device = 0;
+    int width = 0, height = 0, stripe_rows = 8, rank = 0, world_size = 1;
+    int rows_owned = 0;
+    uint32_t n_pixels = 0;
+    double *pixels = nullptr;
+    uint32_t *state = nullptr;
+    unsigned long long *ray_counter = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // begin, after seed, after render
+    bool seeded = false;
+    bool in_flight = false;
+    uint64_t last_samples = 0;
+    int last_variant = 0;
+};
+
+} // namespace rtow
+
+using namespace rtow;
+
+static inline SceneImpl *S(rt_scene *s) { return reinterpret_cast<SceneImpl *>(s); }
+static inline FilmImpl *F(rt_film *f) { return reinterpret_cast<FilmImpl *>(f); }
+
+extern "C" {
+
+int rt_scene_upload(rt_scene *scene, int device)
+{
+    if (!scene) return fail(RT_ERR_INVALID, "rt_scene_upload: null scene");
+    SceneImpl &s = *S(scene);
+    if (!s.committed) return fail(RT_ERR_STATE, "rt_scene_upload: scene not committed (rt_scene_commit)");
+    if (int rc = select_device(device)) return rc;
+    if ((int)s.device.size() <= device) s.device.resize(device + 1, nullptr);
+    if (s.device[device]) return RT_OK;
+    DeviceTables *dt = new DeviceTables;
+    dt->device = device;
+    const FlatScene &f = s.flat;
+    DeviceScene &d = dt->scene;
+    int rc = RT_OK;
+    auto up = [&](auto &host, auto &dev) {
+        if (rc == RT_OK) rc = upload(*dt, host, dev);
+    };
+    up(f.spheres, d.spheres);
+    up(f.sphere_aux, d.sphere_aux);
+    up(f.mspheres, d.mspheres);
+    up(f.msphere_aux, d.msphere_aux);
+    up(f.quads, d.quads);
+    up(f.quad_mat, d.quad_mat);
+    up(f.objects, d.objects);
+    up(f.items, d.items);
+    up(f.xforms, d.xforms);
+    up(f.media, d.media);
+    up(f.nodes, d.nodes);
+    up(f.world_items, d.world_items);
+    up(f.materials, d.materials);
+    up(f.textures, d.textures);
+    up(f.images, d.images);
+    up(f.image_bytes, d.image_bytes);
+    up(f.perlin, d.perlin);
+    if (rc != RT_OK) {
+        release_device_tables(dt);
+        return rc;
+    }
+    d.camera = s.camera;
+    d.world_kind = f.world_kind;
+    d.n_world_items = (uint32_t)f.world_items.size();
+    d.n_nodes = (uint32_t)f.nodes.size();
+    d.n_spheres = (uint32_t)f.spheres.size();
+    d.n_mspheres = (uint32_t)f.mspheres.size();
+    d.n_quads = (uint32_t)f.quads.size();
+    d.n_objects = (uint32_t)f.objects.size();
+    d.flags = f.flags;
+    s.device[device] = dt;
+    return RT_OK;
+}
+
+rt_film *rt_film_create(int device, int width, int height, int stripe_rows, int rank, int world_size)
+{
+    if (width <= 0 || height <= 0 || stripe_rows <= 0 || world_size <= 0 || rank < 0 || rank >= world_size) {
+        set_error("rt_film_create: bad geometry");
+        return nullptr;
+    }
+    if ((int64_t)width * height >= (int64_t)1 << 31) {
+        set_error("rt_film_create: frame too large (pixel index must fit in int like the reference's pixelIndex)");
+        return nullptr;
+    }
+    if (select_device(device) != RT_OK) return nullptr;
+    FilmImpl *f = new FilmImpl;
+    f->device = device;
+    f->width = width;
+    f->height = height;
+    f->stripe_rows = stripe_rows;
+    f->rank = rank;
+    f->world_size = world_size;
+    f->rows_owned = rt_stripe_rows(height, stripe_rows, rank, world_size, nullptr, 0);
+    f->n_pixels = (uint32_t)f->rows_owned * (uint32_t)width;
+    size_t np = f->n_pixels ? f->n_pixels : 1;
+    hipError_t e = hipMalloc((void **)&f->pixels, np * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(f->pixels, 0, np * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->state, np * 6 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreate(&f->ev[k]);
+    if (e != hipSuccess) {
+        hip_fail(e, "rt_film_create allocation");
+        rt_film_destroy(reinterpret_cast<rt_film *>(f));
+        return nullptr;
+    }
+    return reinterpret_cast<rt_film *>(f);
+}
+
+void rt_film_destroy(rt_film *film)
+{
+    if (!film) return;
+    FilmImpl *f = F(film);
+    hipSetDevice(f->device);
+    if (f->pixels) hipFree(f->pixels);
+    if (f->state) hipFree(f->state);
+    if (f->ray_counter) hipFree(f->ray_counter);
+    for (int k = 0; k < 3; k++)
+        if (f->ev[k]) hipEventDestroy(f->ev[k]);
+    if (f->own_stream) hipStreamDestroy(f->own_stream);
+    delete f;
+}
+
+void *rt_film_device_pixels(rt_film *film) { return film ? F(film)->pixels : nullptr; }
+size_t rt_film_pixel_bytes(rt_film *film) { return film ? (size_t)F(film)->n_pixels * 3 * sizeof(double) : 0; }
+
+int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
+{
+    if (!scene || !film || !p) return fail(RT_ERR_INVALID, "rt_render_launch: null argument");
+    SceneImpl &s = *S(scene);
+    FilmImpl &f = *F(film);
+    if (p->width != f.width || p->height != f.height || p->stripe_rows != f.stripe_rows || p->rank != f.rank ||
+        p->world_size != f.world_size || p->device != f.device)
+        return fail(RT_ERR_INVALID, "rt_render_launch: params do not match the film's geometry/device");
+    if (p->samples_per_pixel < 0 || p->max_depth < 0) return fail(RT_ERR_INVALID, "rt_render_launch: negative spp/depth");
+    if (p->variant != 0 && p->variant != 1) return fail(RT_ERR_INVALID, "rt_render_launch: variant must be 0 (strict) or 1 (fast)");
+    if (int rc = rt_scene_upload(scene, f.device)) return rc;
+    if (int rc = select_device(f.device)) return rc;
+    hipStream_t stream = p->stream ? (hipStream_t)p->stream : f.own_stream;
+    const bool keep = (p->flags & RT_FLAG_KEEP_RNG_STATE) && f.seeded;
+
+    HIP_TRY(hipMemsetAsync(f.ray_counter, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(f.ev[0], stream));
+    if (!keep) {
+        SeedArgs sa{};
+        sa.state = f.state;
+        if (int rc = device_jump_table(f.device, &sa.jump_table)) return rc;
+        sa.base = xorwow_seed(p->seed, kSaltCurandDevice);
+        sa.n_pixels = f.n_pixels;
+        sa.width = f.width;
+        sa.stripe_rows = f.stripe_rows;
+        sa.rank = f.rank;
+        sa.world_size = f.world_size;
+        HIP_TRY(p->variant ? launch_seed_fast(sa, stream) : launch_seed_strict(sa, stream));
+        f.seeded = true;
+    }
+    HIP_TRY(hipEventRecord(f.ev[1], stream));
+    RenderArgs ra{};
+    ra.pixels = f.pixels;
+    ra.state = f.state;
+    ra.ray_counter = f.ray_counter;
+    ra.n_pixels = f.n_pixels;
+    ra.width = f.width;
+    ra.height = f.height;
+    ra.rows_owned = f.rows_owned;
+    ra.spp = p->samples_per_pixel;
+    ra.max_depth = p->max_depth;
+    ra.stripe_rows = f.stripe_rows;
+    ra.rank = f.rank;
+    ra.world_size = f.world_size;
+    const DeviceScene &ds = s.device[f.device]->scene;
+    HIP_TRY(p->variant ? launch_render_fast(ds, ra, stream) : launch_render_strict(ds, ra, stream));
+    HIP_TRY(hipEventRecord(f.ev[2], stream));
+    f.last_stream = stream;
+    f.in_flight = true;
+    f.last_samples = (uint64_t)f.n_pixels * (uint64_t)p->samples_per_pixel;
+    f.last_variant = p->variant;
+    return RT_OK;
+}
+
+int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
+{
+    (void)scene;
+    if (!film) return fail(RT_ERR_INVALID, "rt_render_finish: null film");
+    FilmImpl &f = *F(film);
+    if (!f.in_flight) return fail(RT_ERR_STATE, "rt_render_finish: nothing launched");
+    if (int rc = select_device(f.device)) return rc;
+    HIP_TRY(hipEventSynchronize(f.ev[2]));
+    f.in_flight = false;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        float ms_seed = 0, ms_render = 0;
+        HIP_TRY(hipEventElapsedTime(&ms_seed, f.ev[0], f.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms_render, f.ev[1], f.ev[2]));
+        unsigned long long rays = 0;
+        HIP_TRY(hipMemcpy(&rays, f.ray_counter, sizeof rays, hipMemcpyDeviceToHost));
+        stats->samples = f.last_samples;
+        stats->rays = rays;
+        stats->seconds_seed = ms_seed * 1e-3;
+        stats->seconds_render = ms_render * 1e-3;
+        stats->pixels = f.n_pixels;
+        stats->rows = (uint32_t)f.rows_owned;
+        int vg = 0, lds = 0;
+        HIP_TRY(f.last_variant ? kernel_attributes_fast(&vg, &lds) : kernel_attributes_strict(&vg, &lds));
+        stats->kernel_vgprs = (uint32_t)vg;
+        stats->lds_bytes = (uint32_t)lds;
+    }
+    return RT_OK;
+}
+
+int rt_film_download(rt_film *film, double *frame_full, int width, int height)
+{
+    if (!film || !frame_full) return fail(RT_ERR_INVALID, "rt_film_download: null argument");
+    FilmImpl &f = *F(film);
+    if (width != f.width || height != f.height) return fail(RT_ERR_INVALID, "rt_film_download: frame size mismatch");
+    if (int rc = select_device(f.device)) return rc;
+    std::vector<double> compact((size_t)f.n_pixels * 3);
+    if (f.n_pixels) HIP_TRY(hipMemcpy(compact.data(), f.pixels, compact.size() * sizeof(double), hipMemcpyDeviceToHost));
+    size_t lr = 0;
+    for (int j = 0; j < height; j++)
+        if ((j / f.stripe_rows) % f.world_size == f.rank) {
+            std::memcpy(frame_full + (size_t)j * width * 3, compact.data() + lr * (size_t)width * 3, sizeof(double) * (size_t)width * 3);
+            lr++;
+        }
+    return RT_OK;
+}
+
+int rt_render(rt_scene *scene, const rt_render_params *params, double *frame, rt_render_stats *stats)
+{
+    if (!scene || !params || !frame) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    rt_film *film = rt_film_create(params->device, params->width, params->height, params->stripe_rows > 0 ? params->stripe_rows : 8,
+                                   params->rank, params->world_size > 0 ? params->world_size : 1);
+    if (!film) return RT_ERR_HIP;
+    rt_render_params p = *params;
+    if (p.stripe_rows <= 0) p.stripe_rows = 8;
+    if (p.world_size <= 0) p.world_size = 1;
+    int rc = rt_render_launch(scene, film, &p);
+    if (rc == RT_OK) rc = rt_render_finish(scene, film, stats);
+    if (rc == RT_OK) rc = rt_film_download(film, frame, p.width, p.height);
+    rt_film_destroy(film);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,109 @@
+// flat_scene.h -- the SoA scene tables the HIP megakernel reads.  Written by the host flattener
+// (scene_builder.cpp), uploaded once per device (device_scene.cpp), never touched by the oracle.
+//
+// Everything the reference keeps as heap objects with vptrs (R/Hittable.h:33-65, R/Material.h:27-44,
+// R/Texture.h:24-30) becomes a tagged row in one of these tables; virtual dispatch becomes a switch on
+// the tag; the pointer BVH (R/BvhNode.h:165-167) becomes a preorder array with escape links.
+#pragma once
+#include <stdint.h>
+
+namespace rtow {
+
+// ---- references to things that can be hit: (tag << 28) | index ----
+enum : uint32_t {
+    REF_SPHERE = 0u,   // index into spheres
+    REF_MSPHERE = 1u,  // index into moving spheres
+    REF_QUAD = 2u,     // index into quads
+    REF_OBJECT = 3u,   // index into objects (instances / boxes / lists / media)
+    REF_MEDIUM = 4u,   // only in hit results: index into media
+    REF_INNER = 14u,   // BVH node marker: children are the next node and the escape target
+    REF_NONE = 15u
+};
+constexpr uint32_t kRefShift = 28;
+constexpr uint32_t kRefIndexMask = (1u << kRefShift) - 1u;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+static inline constexpr uint32_t make_ref(uint32_t tag, uint32_t index) { return (tag << kRefShift) | index; }
+
+// Sphere (R/Sphere.h:12-20).  geom = what the discriminant test needs; aux = what shading needs.
+struct SphereGeom { double cx, cy, cz, r2; };            // r2 = radius * radius
+struct SphereAux { double inv_r; uint32_t mat; uint32_t pad; };
+
+// MovingSphere (R/MovingSphere.h:19-36): centre(t) = c0 + ((t - t0) / dt) * dc
+struct MSphereGeom { double c0x, c0y, c0z, dcx, dcy, dcz, t0, dt, r2; };
+
+// Quad (R/Quad.h:25-49): plane n.x = d, w = n / (n.n) for the planar coordinates.
+struct QuadGeom { double qx, qy, qz, ux, uy, uz, vx, vy, vz, wx, wy, wz, nx, ny, nz, d; };
+
+// Instance transform step (R/Instance.h:31-37 Translate, :74-112 RotateY).
+enum : uint32_t { XF_TRANSLATE = 0u, XF_ROTATE_Y = 1u };
+struct Xform { double a, b, c; uint32_t kind; uint32_t pad; };  // translate: offset xyz; rotate: a = sin, b = cos
+
+// Composite leaf: [ConstantMedium] -> chain of Translate/RotateY (outermost first) -> geometry.
+enum : uint32_t { GEOM_SINGLE = 0u, GEOM_SPHERES = 1u, GEOM_MSPHERES = 2u, GEOM_QUADS = 3u, GEOM_MIXED = 4u };
+struct ObjectRec {
+    uint32_t geom_kind;  // GEOM_*
+    uint32_t first;      // SINGLE: a prim ref; homogeneous: first prim index; MIXED: first entry of items[]
+    uint32_t count;
+    uint32_t xf_first, xf_count;
+    uint32_t medium;     // index into media or kNone
+    uint32_t pad0, pad1;
+};
+struct MediumRec { double neg_inv_density; uint32_t phase_mat; uint32_t pad; };  // R/ConstantMedium.h:39-44
+
+// Threaded BVH node, preorder.  Inner node: a = b = REF_INNER marker, first child = this + 1.
+// Bottom node (span 1 or 2, R/BvhNode.h:63-72): a, b = leaf refs (a == b for span 1).
+struct BvhNodeRec { double xlo, xhi, ylo, yhi, zlo, zhi; uint32_t a, b, escape, pad; };
+
+// Materials (R/Material.h, R/Metal.h, R/Dielectric.h)
+enum : uint32_t { MAT_LAMBERTIAN = 0u, MAT_METAL = 1u, MAT_DIELECTRIC = 2u, MAT_DIFFUSE_LIGHT = 3u, MAT_ISOTROPIC = 4u };
+struct MaterialRec { double r, g, b, p; uint32_t kind, tex, needs_uv, pad1; };  // metal: rgb + fuzz; dielectric: p = ior
+// needs_uv: the texture tree contains an ImageTexture, the only reader of HitRecord::U/V (R/Texture.h:110-133)
+
+// Textures (R/Texture.h)
+enum : uint32_t { TEX_SOLID = 0u, TEX_CHECKER = 1u, TEX_IMAGE = 2u, TEX_NOISE = 3u };
+struct TextureRec { double r, g, b, s; uint32_t kind, a, b_, pad; };
+// solid: rgb; checker: s = 1/scale, a = even tex, b_ = odd tex; image: a = image index; noise: s = scale, a = perlin index
+struct ImageRec { uint64_t offset; int32_t width, height; };
+struct PerlinRec { double vec[256][3]; int32_t perm_x[256], perm_y[256], perm_z[256]; };  // R/Perlin.h:82-85
+
+// Camera (R/Camera.h:92-101)
+struct CameraRec {
+    double bg[3], origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    double lens_radius, time0, time1;
+};
+
+enum : uint32_t { WORLD_BVH = 0u, WORLD_LIST = 1u };
+
+// What the kernel receives (by value).  All pointers are device pointers.
+struct DeviceScene {
+    const SphereGeom *spheres;
+    const SphereAux *sphere_aux;
+    const MSphereGeom *mspheres;
+    const SphereAux *msphere_aux;
+    const QuadGeom *quads;
+    const uint32_t *quad_mat;
+    const ObjectRec *objects;
+    const uint32_t *items;        // GEOM_MIXED entries (prim refs)
+    const Xform *xforms;
+    const MediumRec *media;
+    const BvhNodeRec *nodes;
+    const uint32_t *world_items;  // WORLD_LIST: leaf refs in list order
+    const MaterialRec *materials;
+    const TextureRec *textures;
+    const ImageRec *images;
+    const unsigned char *image_bytes;
+    const PerlinRec *perlin;
+    CameraRec camera;
+    uint32_t world_kind;
+    uint32_t n_world_items;
+    uint32_t n_nodes;
+    uint32_t n_spheres, n_mspheres, n_quads, n_objects;
+    uint32_t flags;
+};
+
+enum : uint32_t {
+    SCENE_HAS_MEDIA = 1u,
+    SCENE_LIST_ALL_SPHERES = 2u,  // WORLD_LIST whose leaves are spheres 0..n-1 in order (config C2 fast path)
+};
+
+} // namespace rtow

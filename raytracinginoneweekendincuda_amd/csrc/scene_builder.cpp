@@ -1,0 +1,1031 @@
+// scene_builder.cpp -- host side of the construction API (include/rtow.h) and the flattener.
+//
+// The reference builds its world on the device with `new` inside a <<<1,1>>> kernel
+// (R/kernel.cu:176-543).  Here the same constructors run on the host, keep a handle-addressed object
+// graph, and rt_scene_commit() lowers that graph to the SoA tables of flat_scene.h.  All arithmetic
+// that decides geometry (bounding boxes, quad planes, rotation constants, BVH split order) follows
+// the reference expression by expression, in fp64 without contraction, so the tables are bit-identical
+// to what the reference's constructors compute.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/rtow.h"
+#include "scene_host.h"
+
+namespace rtow {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+int fail(int status, const std::string &msg)
+{
+    g_error = msg;
+    return status;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers (R/Vec3.h semantics: v / t is (1 / t) * v)
+// ------------------------------------------------------------------------------------------------
+static inline D3 mk(double x, double y, double z) { return D3{x, y, z}; }
+static inline D3 add(D3 a, D3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline D3 sub(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline D3 neg(D3 a) { return mk(-a.x, -a.y, -a.z); }
+static inline D3 scale(double t, D3 a) { return mk(t * a.x, t * a.y, t * a.z); }
+static inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline D3 cross(D3 u, D3 v) { return mk(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x); }
+static inline double length(D3 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+static inline D3 over(D3 a, double t) { return scale(1 / t, a); }
+static inline D3 normalize(D3 a) { return over(a, length(a)); }
+static inline double comp(D3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
+// ------------------------------------------------------------------------------------------------
+// boxes (R/AABB.h, R/Interval.h)
+// ------------------------------------------------------------------------------------------------
+static Box empty_box()
+{
+    Box b;
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = +DBL_MAX;
+        b.hi[k] = -DBL_MAX;
+    }
+    return b;
+}
+static void pad_thin_axes(Box &b)  // AABB.h:114-120
+{
+    const double delta = 0.0001;
+    for (int k = 0; k < 3; k++)
+        if (b.hi[k] - b.lo[k] < delta) {
+            double half = delta / 2.0;
+            b.lo[k] = b.lo[k] - half;
+            b.hi[k] = b.hi[k] + half;
+        }
+}
+static Box box_from_corners(D3 a, D3 b)  // AABB.h:34-40
+{
+    Box r;
+    for (int k = 0; k < 3; k++) {
+        double p = comp(a, k), q = comp(b, k);
+        if (p <= q) {
+            r.lo[k] = p;
+            r.hi[k] = q;
+        } else {
+            r.lo[k] = q;
+            r.hi[k] = p;
+        }
+    }
+    pad_thin_axes(r);
+    return r;
+}
+static Box box_merge(const Box &a, const Box &b)  // AABB.h:43-48 (no padding)
+{
+    Box r;
+    for (int k = 0; k < 3; k++) {
+        r.lo[k] = a.lo[k] <= b.lo[k] ? a.lo[k] : b.lo[k];
+        r.hi[k] = a.hi[k] >= b.hi[k] ? a.hi[k] : b.hi[k];
+    }
+    return r;
+}
+static Box box_moved(const Box &b, D3 off)  // AABB.h:127-130 (interval ctor pads again)
+{
+    Box r;
+    for (int k = 0; k < 3; k++) {
+        r.lo[k] = b.lo[k] + comp(off, k);
+        r.hi[k] = b.hi[k] + comp(off, k);
+    }
+    pad_thin_axes(r);
+    return r;
+}
+static int longest_axis(const Box &b)  // AABB.h:101-107
+{
+    double sx = b.hi[0] - b.lo[0], sy = b.hi[1] - b.lo[1], sz = b.hi[2] - b.lo[2];
+    if (sx > sy) return sx > sz ? 0 : 2;
+    return sy > sz ? 1 : 2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host RNG jump table: T^(2^67 * g * 16^k) for g = 1..15, k = 0..15
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Gf2 {
+    uint32_t row[160][5];
+};
+void gf2_mul_vec(const Gf2 &m, const uint32_t in[5], uint32_t out[5])
+{
+    uint32_t acc[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 160; i++)
+        if ((in[i >> 5] >> (i & 31)) & 1u)
+            for (int k = 0; k < 5; k++) acc[k] ^= m.row[i][k];
+    std::memcpy(out, acc, sizeof acc);
+}
+// r = a after b (apply b first, then a): row_i(r) = a(row_i(b))
+void gf2_compose(const Gf2 &a, const Gf2 &b, Gf2 &r)
+{
+    for (int i = 0; i < 160; i++) gf2_mul_vec(a, b.row[i], r.row[i]);
+}
+std::vector<uint32_t> build_jump_table()
+{
+    std::vector<uint32_t> table(kJumpTableWords);
+    Gf2 *cur = new Gf2, *tmp = new Gf2, *pw = new Gf2;
+    for (int i = 0; i < 160; i++) {
+        Xorwow s{0, 0, 0, 0, 0, 0};
+        uint32_t *w = &s.v0;
+        w[i >> 5] = 1u << (i & 31);
+        xorwow_next(s);
+        cur->row[i][0] = s.v0; cur->row[i][1] = s.v1; cur->row[i][2] = s.v2; cur->row[i][3] = s.v3; cur->row[i][4] = s.v4;
+    }
+    for (int k = 0; k < 67; k++) {  // T^(2^67)
+        gf2_compose(*cur, *cur, *tmp);
+        std::swap(cur, tmp);
+    }
+    for (int k = 0; k < kJumpDigits; k++) {
+        // cur = J^(16^k); fill g = 1..15 by repeated composition
+        *pw = *cur;
+        for (int g = 1; g <= 15; g++) {
+            std::memcpy(&table[((size_t)k * 15 + (g - 1)) * kJumpMatrixWords], pw->row, sizeof pw->row);
+            if (g < 15) {
+                gf2_compose(*cur, *pw, *tmp);
+                *pw = *tmp;
+            }
+        }
+        gf2_compose(*cur, *pw, *tmp);  // J^(16^k * 16)
+        *cur = *tmp;
+    }
+    delete cur;
+    delete tmp;
+    delete pw;
+    return table;
+}
+} // namespace
+
+const uint32_t *host_jump_table()
+{
+    static std::once_flag once;
+    static std::vector<uint32_t> table;
+    std::call_once(once, [] { table = build_jump_table(); });
+    return table.data();
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph access helpers
+// ------------------------------------------------------------------------------------------------
+static HostHittable *get_h(SceneImpl *s, rt_handle h)
+{
+    if (!s || h == 0 || h > s->hittables.size()) return nullptr;
+    return &s->hittables[h - 1];
+}
+static bool valid_mat(SceneImpl *s, rt_handle m) { return s && m >= 1 && m <= s->materials.size(); }
+static bool valid_tex(SceneImpl *s, rt_handle t) { return s && t >= 1 && t <= s->textures.size(); }
+static rt_handle push_h(SceneImpl *s, HostHittable &&h)
+{
+    s->committed = false;
+    s->hittables.push_back(std::move(h));
+    return (rt_handle)s->hittables.size();
+}
+static rt_handle push_tex(SceneImpl *s, const HostTexture &t)
+{
+    s->committed = false;
+    s->textures.push_back(t);
+    return (rt_handle)s->textures.size();
+}
+static rt_handle push_mat(SceneImpl *s, const HostMaterial &m)
+{
+    s->committed = false;
+    s->materials.push_back(m);
+    return (rt_handle)s->materials.size();
+}
+
+// ------------------------------------------------------------------------------------------------
+// BVH construction: R/BvhNode.h:50-90 (recursive median split) + :170-193 (stable insertion sort)
+// ------------------------------------------------------------------------------------------------
+static int build_tree(SceneImpl *s, HostHittable &bvh, std::vector<uint32_t> &objs, int start, int end)
+{
+    int me = (int)bvh.tree.size();
+    bvh.tree.push_back({});
+    Box box = empty_box();
+    for (int i = start; i < end; i++) box = box_merge(box, s->hittables[objs[i] - 1].box);
+    int axis = longest_axis(box);
+    int span = end - start;
+    HostHittable::TreeNode node{};
+    node.box = box;
+    node.left = node.right = -1;
+    if (span == 1) {
+        node.leaf_a = node.leaf_b = objs[start];
+    } else if (span == 2) {
+        node.leaf_a = objs[start];
+        node.leaf_b = objs[start + 1];
+    } else {
+        for (int i = start + 1; i < end; i++) {
+            uint32_t key = objs[i];
+            double key_min = s->hittables[key - 1].box.lo[axis];
+            int j = i - 1;
+            while (j >= start && key_min < s->hittables[objs[j] - 1].box.lo[axis]) {
+                objs[j + 1] = objs[j];
+                j--;
+            }
+            objs[j + 1] = key;
+        }
+        int mid = start + span / 2;
+        node.left = build_tree(s, bvh, objs, start, mid);
+        node.right = build_tree(s, bvh, objs, mid, end);
+    }
+    bvh.tree[me] = node;
+    return me;
+}
+
+// ------------------------------------------------------------------------------------------------
+// flattening
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Flattener {
+    SceneImpl &s;
+    FlatScene &f;
+    std::string err;
+
+    uint32_t add_primitive(const HostHittable &h)
+    {
+        if (h.kind == HKind::Sphere) {
+            f.spheres.push_back({h.c0.x, h.c0.y, h.c0.z, h.radius * h.radius});
+            f.sphere_aux.push_back({1 / h.radius, h.material - 1, 0});
+            return make_ref(REF_SPHERE, (uint32_t)f.spheres.size() - 1);
+        }
+        if (h.kind == HKind::MovingSphere) {
+            D3 dc = sub(h.c1, h.c0);
+            f.mspheres.push_back({h.c0.x, h.c0.y, h.c0.z, dc.x, dc.y, dc.z, h.t0, h.t1 - h.t0, h.radius * h.radius});
+            f.msphere_aux.push_back({1 / h.radius, h.material - 1, 0});
+            return make_ref(REF_MSPHERE, (uint32_t)f.mspheres.size() - 1);
+        }
+        f.quads.push_back({h.q.x, h.q.y, h.q.z, h.u.x, h.u.y, h.u.z, h.v.x, h.v.y, h.v.z, h.w.x, h.w.y, h.w.z,
+                           h.normal.x, h.normal.y, h.normal.z, h.plane_d});
+        f.quad_mat.push_back(h.material - 1);
+        return make_ref(REF_QUAD, (uint32_t)f.quads.size() - 1);
+    }
+
+    static bool is_primitive(HKind k) { return k == HKind::Sphere || k == HKind::MovingSphere || k == HKind::Quad; }
+
+    // Collect the primitives of a (possibly nested) list in visiting order.  A closest-hit scan over a
+    // nested list equals the scan over its flattened sequence (R/HittableList.h:39-57 keeps one running
+    // closestSoFar), provided the members draw no random numbers -- i.e. are primitives.
+    bool collect_list(uint32_t handle, std::vector<uint32_t> &prims)
+    {
+        const HostHittable &h = s.hittables[handle - 1];
+        if (is_primitive(h.kind)) {
+            prims.push_back(handle);
+            return true;
+        }
+        if (h.kind == HKind::List || h.kind == HKind::Bvh) {
+            // A nested BvhNode over primitives returns the same closest hit as a scan of its leaves.
+            for (uint32_t c : h.items)
+                if (!collect_list(c, prims)) return false;
+            return true;
+        }
+        err = "unsupported nesting: a list/BVH inside an instance or medium may only contain primitives and lists";
+        return false;
+    }
+
+    // Lower one world leaf to a ref.
+    uint32_t lower_leaf(uint32_t handle)
+    {
+        const HostHittable *h = &s.hittables[handle - 1];
+        if (is_primitive(h->kind)) return add_primitive(*h);
+
+        ObjectRec obj{};
+        obj.medium = kNone;
+        if (h->kind == HKind::Medium) {
+            f.media.push_back({h->neg_inv_density, h->material - 1, 0});
+            obj.medium = (uint32_t)f.media.size() - 1;
+            f.flags |= SCENE_HAS_MEDIA;
+            h = &s.hittables[h->child - 1];
+            if (h->kind == HKind::Medium) {
+                err = "unsupported nesting: ConstantMedium directly inside ConstantMedium";
+                return kNone;
+            }
+        }
+        obj.xf_first = (uint32_t)f.xforms.size();
+        while (h->kind == HKind::Translate || h->kind == HKind::RotateY) {
+            if (h->kind == HKind::Translate)
+                f.xforms.push_back({h->offset.x, h->offset.y, h->offset.z, XF_TRANSLATE, 0});
+            else
+                f.xforms.push_back({h->sin_t, h->cos_t, 0.0, XF_ROTATE_Y, 0});
+            obj.xf_count++;
+            h = &s.hittables[h->child - 1];
+        }
+        if (obj.xf_count > 8) {
+            err = "unsupported nesting: more than 8 chained instance transforms";
+            return kNone;
+        }
+        if (h->kind == HKind::Medium) {
+            err = "unsupported nesting: ConstantMedium inside an instance transform";
+            return kNone;
+        }
+        if (is_primitive(h->kind)) {
+            obj.geom_kind = GEOM_SINGLE;
+            obj.first = add_primitive(*h);
+            obj.count = 1;
+        } else {
+            std::vector<uint32_t> prims;
+            uint32_t self = (uint32_t)(h - s.hittables.data()) + 1;
+            if (!collect_list(self, prims)) return kNone;
+            bool all_s = true, all_m = true, all_q = true;
+            for (uint32_t p : prims) {
+                HKind k = s.hittables[p - 1].kind;
+                all_s &= k == HKind::Sphere;
+                all_m &= k == HKind::MovingSphere;
+                all_q &= k == HKind::Quad;
+            }
+            obj.count = (uint32_t)prims.size();
+            if (prims.empty()) {
+                obj.geom_kind = GEOM_MIXED;
+                obj.first = (uint32_t)f.items.size();
+            } else if (all_s || all_m || all_q) {
+                obj.geom_kind = all_s ? GEOM_SPHERES : (all_m ? GEOM_MSPHERES : GEOM_QUADS);
+                uint32_t first_ref = add_primitive(s.hittables[prims[0] - 1]);
+                obj.first = first_ref & kRefIndexMask;
+                for (size_t k = 1; k < prims.size(); k++) add_primitive(s.hittables[prims[k] - 1]);
+            } else {
+                obj.geom_kind = GEOM_MIXED;
+                std::vector<uint32_t> refs;
+                for (uint32_t p : prims) refs.push_back(add_primitive(s.hittables[p - 1]));
+                obj.first = (uint32_t)f.items.size();
+                f.items.insert(f.items.end(), refs.begin(), refs.end());
+            }
+        }
+        f.objects.push_back(obj);
+        return make_ref(REF_OBJECT, (uint32_t)f.objects.size() - 1);
+    }
+
+    // Thread the reference's traversal (R/BvhNode.h:101-158) into escape links.  The reference visits
+    // a node, tests leaf children on the spot, descends into the first inner child and stacks the
+    // second; the stack therefore always holds the right siblings of the current root path, so "pop"
+    // is a static successor: the escape link.
+    uint32_t thread_tree(const HostHittable &bvh, int ti, uint32_t escape, const std::vector<uint32_t> &leaf_ref_of_handle)
+    {
+        const auto &tn = bvh.tree[ti];
+        uint32_t me = (uint32_t)f.nodes.size();
+        f.nodes.push_back({});
+        BvhNodeRec rec{};
+        rec.xlo = tn.box.lo[0]; rec.xhi = tn.box.hi[0];
+        rec.ylo = tn.box.lo[1]; rec.yhi = tn.box.hi[1];
+        rec.zlo = tn.box.lo[2]; rec.zhi = tn.box.hi[2];
+        rec.escape = escape;
+        if (tn.left < 0) {
+            rec.a = leaf_ref_of_handle[tn.leaf_a];
+            rec.b = leaf_ref_of_handle[tn.leaf_b];
+            f.nodes[me] = rec;
+            return me;
+        }
+        rec.a = rec.b = make_ref(REF_INNER, 0);
+        f.nodes[me] = rec;
+        // left subtree occupies [me+1, right_index); its escape is the right child
+        // we do not know right_index until the left subtree is emitted: patch afterwards
+        size_t left_begin = f.nodes.size();
+        thread_tree(bvh, tn.left, kNone - 1 /* placeholder */, leaf_ref_of_handle);
+        uint32_t right_index = (uint32_t)f.nodes.size();
+        for (size_t k = left_begin; k < right_index; k++)
+            if (f.nodes[k].escape == kNone - 1) f.nodes[k].escape = right_index;
+        thread_tree(bvh, tn.right, escape, leaf_ref_of_handle);
+        return me;
+    }
+};
+} // namespace
+
+static void lower_materials(SceneImpl &s, FlatScene &f)
+{
+    f.materials.clear();
+    f.textures.clear();
+    for (const HostTexture &t : s.textures) {
+        TextureRec r{};
+        r.kind = t.kind;
+        r.r = t.color.x; r.g = t.color.y; r.b = t.color.z;
+        r.s = t.s;
+        if (t.kind == TEX_CHECKER) {
+            r.a = t.a - 1;
+            r.b_ = t.b - 1;
+        } else {
+            r.a = t.a;
+        }
+        f.textures.push_back(r);
+    }
+    for (const HostMaterial &m : s.materials) {
+        MaterialRec r{};
+        r.kind = m.kind;
+        r.tex = m.texture ? m.texture - 1 : kNone;
+        r.r = m.albedo.x; r.g = m.albedo.y; r.b = m.albedo.z;
+        r.p = m.p;
+        // U/V are only ever read by ImageTexture::Value; find out whether this material can reach one
+        std::vector<uint32_t> todo;
+        if (m.texture) todo.push_back(m.texture);
+        while (!todo.empty()) {
+            const HostTexture &t = s.textures[todo.back() - 1];
+            todo.pop_back();
+            if (t.kind == TEX_IMAGE) r.needs_uv = 1;
+            if (t.kind == TEX_CHECKER) {
+                todo.push_back(t.a);
+                todo.push_back(t.b);
+            }
+        }
+        f.materials.push_back(r);
+    }
+    f.images = s.images;
+    f.image_bytes = s.image_bytes;
+    f.perlin = s.perlin;
+}
+
+int flatten_scene(SceneImpl &s)
+{
+    if (s.world == 0) return fail(RT_ERR_STATE, "rt_scene_commit: no world set (rt_scene_set_world)");
+    if (!s.has_camera) return fail(RT_ERR_STATE, "rt_scene_commit: no camera set (rt_scene_set_camera)");
+    s.flat = FlatScene{};
+    FlatScene &f = s.flat;
+    lower_materials(s, f);
+    Flattener fl{s, f, {}};
+
+    const HostHittable &world = s.hittables[s.world - 1];
+    std::vector<uint32_t> leaves;  // hittable handles, final order
+    if (world.kind == HKind::Bvh) {
+        f.world_kind = WORLD_BVH;
+        leaves = world.items;
+    } else if (world.kind == HKind::List) {
+        f.world_kind = WORLD_LIST;
+        leaves = world.items;
+    } else {
+        f.world_kind = WORLD_LIST;  // a lone hittable as world behaves as a list of one
+        leaves.push_back(s.world);
+    }
+    for (uint32_t h : leaves) {
+        HKind k = s.hittables[h - 1].kind;
+        if (world.kind == HKind::List && (k == HKind::List)) {
+            // list inside the world list: keep as a composite leaf (boxes), handled by lower_leaf
+        }
+        if (k == HKind::Bvh && world.kind != HKind::Bvh)
+            return fail(RT_ERR_UNSUPPORTED, "unsupported nesting: BvhNode inside a list world");
+    }
+    std::vector<uint32_t> ref_of_handle(s.hittables.size() + 1, kNone);
+    for (uint32_t h : leaves) {
+        uint32_t ref = fl.lower_leaf(h);
+        if (ref == kNone) return fail(RT_ERR_UNSUPPORTED, fl.err);
+        ref_of_handle[h] = ref;
+        f.world_items.push_back(ref);
+        f.leaf_boxes.push_back(s.hittables[h - 1].box);
+    }
+    if (f.world_kind == WORLD_BVH) {
+        if (world.tree.empty()) return fail(RT_ERR_INVALID, "BvhNode world has no nodes");
+        fl.thread_tree(world, 0, kNone, ref_of_handle);
+    } else {
+        bool all_spheres = !f.world_items.empty();
+        for (size_t k = 0; k < f.world_items.size(); k++) all_spheres &= f.world_items[k] == make_ref(REF_SPHERE, (uint32_t)k);
+        if (all_spheres && f.spheres.size() == f.world_items.size()) f.flags |= SCENE_LIST_ALL_SPHERES;
+    }
+    s.committed = true;
+    return RT_OK;
+}
+
+SceneImpl::~SceneImpl()
+{
+    for (DeviceTables *t : device)
+        if (t) release_device_tables(t);
+}
+
+} // namespace rtow
+
+// ================================================================================================
+// C-ABI: construction
+// ================================================================================================
+using namespace rtow;
+
+static inline SceneImpl *S(rt_scene *s) { return reinterpret_cast<SceneImpl *>(s); }
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+const char *rt_version(void) { return "rtow-hip 0.1 (gfx950)"; }
+
+rt_rng *rt_rng_create_salted(uint64_t seed, uint64_t sequence, int salt_kind)
+{
+    RngImpl *r = new RngImpl;
+    r->state = xorwow_seed(seed, salt_kind ? kSaltRocrand : kSaltCurandDevice);
+    if (sequence) xorwow_skip_sequences(host_jump_table(), sequence, r->state);
+    return reinterpret_cast<rt_rng *>(r);
+}
+rt_rng *rt_rng_create(uint64_t seed, uint64_t sequence) { return rt_rng_create_salted(seed, sequence, 0); }
+void rt_rng_destroy(rt_rng *rng) { delete reinterpret_cast<RngImpl *>(rng); }
+float rt_rng_uniform(rt_rng *rng) { return xorwow_uniform(reinterpret_cast<RngImpl *>(rng)->state); }
+uint32_t rt_rng_next_u32(rt_rng *rng) { return xorwow_next(reinterpret_cast<RngImpl *>(rng)->state); }
+void rt_rng_state(const rt_rng *rng, uint32_t out6[6])
+{
+    const Xorwow &s = reinterpret_cast<const RngImpl *>(rng)->state;
+    out6[0] = s.d; out6[1] = s.v0; out6[2] = s.v1; out6[3] = s.v2; out6[4] = s.v3; out6[5] = s.v4;
+}
+
+rt_scene *rt_scene_create(void) { return reinterpret_cast<rt_scene *>(new SceneImpl); }
+void rt_scene_destroy(rt_scene *scene) { delete S(scene); }
+
+// ---- textures ----
+rt_handle rt_solid_color(rt_scene *s, double r, double g, double b)
+{
+    if (!s) return 0;
+    HostTexture t{};
+    t.kind = TEX_SOLID;
+    t.color = mk(r, g, b);
+    return push_tex(S(s), t);
+}
+rt_handle rt_checker_texture(rt_scene *s, double scale, rt_handle even, rt_handle odd)
+{
+    if (!valid_tex(S(s), even) || !valid_tex(S(s), odd)) {
+        set_error("rt_checker_texture: invalid texture handle");
+        return 0;
+    }
+    HostTexture t{};
+    t.kind = TEX_CHECKER;
+    t.s = 1.0 / scale;  // Texture.h:64
+    t.a = even;
+    t.b = odd;
+    return push_tex(S(s), t);
+}
+rt_handle rt_image_texture(rt_scene *s, const unsigned char *rgb, int width, int height)
+{
+    if (!s) return 0;
+    SceneImpl *sc = S(s);
+    ImageRec im{};
+    im.offset = sc->image_bytes.size();
+    if (rgb && width > 0 && height > 0) {
+        im.width = width;
+        im.height = height;
+        sc->image_bytes.insert(sc->image_bytes.end(), rgb, rgb + (size_t)width * height * 3);
+    } else {
+        im.width = 0;
+        im.height = 0;  // Texture.h:113-114: no data => cyan
+    }
+    sc->images.push_back(im);
+    HostTexture t{};
+    t.kind = TEX_IMAGE;
+    t.a = (uint32_t)sc->images.size() - 1;
+    return push_tex(sc, t);
+}
+rt_handle rt_noise_texture(rt_scene *s, double scale, rt_rng *rng)
+{
+    if (!s || !rng) {
+        set_error("rt_noise_texture: scene and rng are required");
+        return 0;
+    }
+    SceneImpl *sc = S(s);
+    Xorwow &st = reinterpret_cast<RngImpl *>(rng)->state;
+    PerlinRec p{};
+    // Perlin.h:27-35: 256 unit vectors from RandomVector(-1, 1) (arguments drawn left to right), then
+    // three Fisher-Yates permutations (Perlin.h:105-116: int(uniform * (i + 1)) in fp32, clamped to i).
+    for (int i = 0; i < 256; i++) {
+        double range = 1.0 - (-1.0);
+        double a = -1.0 + range * (double)xorwow_uniform(st);
+        double b = -1.0 + range * (double)xorwow_uniform(st);
+        double c = -1.0 + range * (double)xorwow_uniform(st);
+        D3 u = normalize(mk(a, b, c));
+        p.vec[i][0] = u.x; p.vec[i][1] = u.y; p.vec[i][2] = u.z;
+    }
+    int32_t *perms[3] = {p.perm_x, p.perm_y, p.perm_z};
+    for (int t = 0; t < 3; t++) {
+        int32_t *q = perms[t];
+        for (int i = 0; i < 256; i++) q[i] = i;
+        for (int i = 255; i > 0; i--) {
+            int target = (int)(xorwow_uniform(st) * (float)(i + 1));
+            if (target > i) target = i;
+            int32_t tmp = q[i];
+            q[i] = q[target];
+            q[target] = tmp;
+        }
+    }
+    sc->perlin.push_back(p);
+    HostTexture t{};
+    t.kind = TEX_NOISE;
+    t.s = scale;
+    t.a = (uint32_t)sc->perlin.size() - 1;
+    return push_tex(sc, t);
+}
+
+// ---- materials ----
+static rt_handle textured_material(rt_scene *s, uint32_t kind, rt_handle tex, const char *who)
+{
+    if (!valid_tex(S(s), tex)) {
+        set_error(std::string(who) + ": invalid texture handle");
+        return 0;
+    }
+    HostMaterial m{};
+    m.kind = kind;
+    m.texture = tex;
+    return push_mat(S(s), m);
+}
+rt_handle rt_lambertian_tex(rt_scene *s, rt_handle texture) { return textured_material(s, MAT_LAMBERTIAN, texture, "rt_lambertian_tex"); }
+rt_handle rt_lambertian(rt_scene *s, double r, double g, double b) { return s ? rt_lambertian_tex(s, rt_solid_color(s, r, g, b)) : 0; }
+rt_handle rt_diffuse_light_tex(rt_scene *s, rt_handle texture) { return textured_material(s, MAT_DIFFUSE_LIGHT, texture, "rt_diffuse_light_tex"); }
+rt_handle rt_diffuse_light(rt_scene *s, double r, double g, double b) { return s ? rt_diffuse_light_tex(s, rt_solid_color(s, r, g, b)) : 0; }
+rt_handle rt_isotropic_tex(rt_scene *s, rt_handle texture) { return textured_material(s, MAT_ISOTROPIC, texture, "rt_isotropic_tex"); }
+rt_handle rt_isotropic(rt_scene *s, double r, double g, double b) { return s ? rt_isotropic_tex(s, rt_solid_color(s, r, g, b)) : 0; }
+rt_handle rt_metal(rt_scene *s, double r, double g, double b, double fuzz)
+{
+    if (!s) return 0;
+    HostMaterial m{};
+    m.kind = MAT_METAL;
+    m.albedo = mk(r, g, b);
+    m.p = fuzz < 1.0 ? fuzz : 1.0;  // Metal.h:14
+    return push_mat(S(s), m);
+}
+rt_handle rt_dielectric(rt_scene *s, double refraction_index)
+{
+    if (!s) return 0;
+    HostMaterial m{};
+    m.kind = MAT_DIELECTRIC;
+    m.p = refraction_index;
+    return push_mat(S(s), m);
+}
+
+// ---- hittables ----
+rt_handle rt_sphere(rt_scene *s, double cx, double cy, double cz, double radius, rt_handle material)
+{
+    if (!valid_mat(S(s), material)) {
+        set_error("rt_sphere: invalid material handle");
+        return 0;
+    }
+    HostHittable h{};
+    h.kind = HKind::Sphere;
+    h.c0 = mk(cx, cy, cz);
+    h.radius = radius;
+    h.material = material;
+    D3 rv = mk(radius, radius, radius);
+    h.box = box_from_corners(sub(h.c0, rv), add(h.c0, rv));  // Sphere.h:18-19
+    return push_h(S(s), std::move(h));
+}
+rt_handle rt_moving_sphere(rt_scene *s, double c0x, double c0y, double c0z, double c1x, double c1y, double c1z,
+                           double time0, double time1, double radius, rt_handle material)
+{
+    if (!valid_mat(S(s), material)) {
+        set_error("rt_moving_sphere: invalid material handle");
+        return 0;
+    }
+    HostHittable h{};
+    h.kind = HKind::MovingSphere;
+    h.c0 = mk(c0x, c0y, c0z);
+    h.c1 = mk(c1x, c1y, c1z);
+    h.t0 = time0;
+    h.t1 = time1;
+    h.radius = radius;
+    h.material = material;
+    D3 rv = mk(radius, radius, radius);
+    Box b0 = box_from_corners(sub(h.c0, rv), add(h.c0, rv));
+    Box b1 = box_from_corners(sub(h.c1, rv), add(h.c1, rv));
+    h.box = box_merge(b0, b1);  // MovingSphere.h:32-35
+    return push_h(S(s), std::move(h));
+}
+rt_handle rt_quad(rt_scene *s, const double q[3], const double u[3], const double v[3], rt_handle material)
+{
+    if (!valid_mat(S(s), material) || !q || !u || !v) {
+        set_error("rt_quad: invalid material handle or null vector");
+        return 0;
+    }
+    HostHittable h{};
+    h.kind = HKind::Quad;
+    h.q = mk(q[0], q[1], q[2]);
+    h.u = mk(u[0], u[1], u[2]);
+    h.v = mk(v[0], v[1], v[2]);
+    h.material = material;
+    D3 n = cross(h.u, h.v);  // Quad.h:33-37
+    h.normal = normalize(n);
+    h.plane_d = dot(h.normal, h.q);
+    h.w = over(n, dot(n, n));
+    Box d1 = box_from_corners(h.q, add(add(h.q, h.u), h.v));  // Quad.h:44-49
+    Box d2 = box_from_corners(add(h.q, h.u), add(h.q, h.v));
+    h.box = box_merge(d1, d2);
+    return push_h(S(s), std::move(h));
+}
+rt_handle rt_translate(rt_scene *s, rt_handle object, double ox, double oy, double oz)
+{
+    HostHittable *c = get_h(S(s), object);
+    if (!c) {
+        set_error("rt_translate: invalid object handle");
+        return 0;
+    }
+    HostHittable h{};
+    h.kind = HKind::Translate;
+    h.child = object;
+    h.offset = mk(ox, oy, oz);
+    h.box = box_moved(c->box, h.offset);  // Instance.h:36
+    return push_h(S(s), std::move(h));
+}
+rt_handle rt_rotate_y(rt_scene *s, rt_handle object, double angle_degrees)
+{
+    HostHittable *c = get_h(S(s), object);
+    if (!c) {
+        set_error("rt_rotate_y: invalid object handle");
+        return 0;
+    }
+    HostHittable h{};
+    h.kind = HKind::RotateY;
+    h.child = object;
+    double radians = angle_degrees * 3.1415926535897932385 / 180.0;  // Instance.h:78-80
+    h.sin_t = std::sin(radians);
+    h.cos_t = std::cos(radians);
+    const Box cb = c->box;
+    double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (int i = 0; i < 2; i++)  // Instance.h:87-109: rotate the 8 corners
+        for (int j = 0; j < 2; j++)
+            for (int k = 0; k < 2; k++) {
+                double x = i * cb.hi[0] + (1 - i) * cb.lo[0];
+                double y = j * cb.hi[1] + (1 - j) * cb.lo[1];
+                double z = k * cb.hi[2] + (1 - k) * cb.lo[2];
+                double nx = h.cos_t * x + h.sin_t * z;
+                double nz = -h.sin_t * x + h.cos_t * z;
+                double t[3] = {nx, y, nz};
+                for (int c2 = 0; c2 < 3; c2++) {
+                    mn[c2] = std::fmin(mn[c2], t[c2]);
+                    mx[c2] = std::fmax(mx[c2], t[c2]);
+                }
+            }
+    h.box = box_from_corners(mk(mn[0], mn[1], mn[2]), mk(mx[0], mx[1], mx[2]));
+    return push_h(S(s), std::move(h));
+}
+rt_handle rt_hittable_list(rt_scene *s, const rt_handle *objects, int count)
+{
+    if (!s || count < 0 || (count > 0 && !objects)) {
+        set_error("rt_hittable_list: bad arguments");
+        return 0;
+    }
+    HostHittable h{};
+    h.kind = HKind::List;
+    h.box = empty_box();
+    for (int i = 0; i < count; i++) {
+        HostHittable *c = get_h(S(s), objects[i]);
+        if (!c) {
+            set_error("rt_hittable_list: invalid child handle");
+            return 0;
+        }
+        h.box = box_merge(h.box, c->box);  // HittableList.h:25-26
+        h.items.push_back(objects[i]);
+    }
+    return push_h(S(s), std::move(h));
+}
+rt_handle rt_make_box(rt_scene *s, const double a[3], const double b[3], rt_handle material)
+{
+    if (!valid_mat(S(s), material) || !a || !b) {
+        set_error("rt_make_box: invalid material handle or null corner");
+        return 0;
+    }
+    // Instance.h:166-184: six quads, in the reference's order and with its (negated) edge vectors.
+    double mn[3], mx[3];
+    for (int k = 0; k < 3; k++) {
+        mn[k] = std::fmin(a[k], b[k]);
+        mx[k] = std::fmax(a[k], b[k]);
+    }
+    D3 dx = mk(mx[0] - mn[0], 0, 0), dy = mk(0, mx[1] - mn[1], 0), dz = mk(0, 0, mx[2] - mn[2]);
+    D3 ndx = neg(dx), ndz = neg(dz);
+    struct Side { double q[3]; D3 u, v; } sides[6] = {
+        {{mn[0], mn[1], mx[2]}, dx, dy},    // front
+        {{mx[0], mn[1], mx[2]}, ndz, dy},   // right
+        {{mx[0], mn[1], mn[2]}, ndx, dy},   // back
+        {{mn[0], mn[1], mn[2]}, dz, dy},    // left
+        {{mn[0], mx[1], mx[2]}, dx, ndz},   // top
+        {{mn[0], mn[1], mn[2]}, dx, dz},    // bottom
+    };
+    rt_handle quads[6];
+    for (int k = 0; k < 6; k++) {
+        double u[3] = {sides[k].u.x, sides[k].u.y, sides[k].u.z}, v[3] = {sides[k].v.x, sides[k].v.y, sides[k].v.z};
+        quads[k] = rt_quad(s, sides[k].q, u, v, material);
+        if (!quads[k]) return 0;
+    }
+    return rt_hittable_list(s, quads, 6);
+}
+static rt_handle medium_common(rt_scene *s, rt_handle boundary, double density, rt_handle phase)
+{
+    HostHittable *c = get_h(S(s), boundary);
+    if (!c || !phase) {
+        set_error("rt_constant_medium: invalid boundary or texture handle");
+        return 0;
+    }
+    HostHittable h{};
+    h.kind = HKind::Medium;
+    h.child = boundary;
+    h.neg_inv_density = -1.0 / density;  // ConstantMedium.h:41
+    h.material = phase;
+    h.box = c->box;  // ConstantMedium.h:96
+    return push_h(S(s), std::move(h));
+}
+rt_handle rt_constant_medium(rt_scene *s, rt_handle boundary, double density, double r, double g, double b)
+{
+    if (!s) return 0;
+    return medium_common(s, boundary, density, rt_isotropic(s, r, g, b));
+}
+rt_handle rt_constant_medium_tex(rt_scene *s, rt_handle boundary, double density, rt_handle texture)
+{
+    if (!s) return 0;
+    return medium_common(s, boundary, density, rt_isotropic_tex(s, texture));
+}
+rt_handle rt_bvh_node(rt_scene *s, rt_handle *objects, int count)
+{
+    if (!s || !objects || count <= 0) {
+        set_error("rt_bvh_node: needs at least one object (the reference's constructor does not terminate on an empty span)");
+        return 0;
+    }
+    SceneImpl *sc = S(s);
+    for (int i = 0; i < count; i++)
+        if (!get_h(sc, objects[i])) {
+            set_error("rt_bvh_node: invalid object handle");
+            return 0;
+        }
+    HostHittable h{};
+    h.kind = HKind::Bvh;
+    std::vector<uint32_t> objs(objects, objects + count);
+    build_tree(sc, h, objs, 0, count);
+    h.box = h.tree[0].box;
+    h.items = objs;
+    std::memcpy(objects, objs.data(), sizeof(rt_handle) * (size_t)count);  // the reference sorts list[] in place
+    return push_h(sc, std::move(h));
+}
+int rt_hittable_bounding_box(rt_scene *s, rt_handle object, double out[6])
+{
+    HostHittable *h = get_h(S(s), object);
+    if (!h || !out) return fail(RT_ERR_INVALID, "rt_hittable_bounding_box: invalid handle");
+    for (int k = 0; k < 3; k++) {
+        out[2 * k] = h->box.lo[k];
+        out[2 * k + 1] = h->box.hi[k];
+    }
+    return RT_OK;
+}
+
+int rt_scene_set_world(rt_scene *s, rt_handle world)
+{
+    if (!get_h(S(s), world)) return fail(RT_ERR_INVALID, "rt_scene_set_world: invalid handle");
+    S(s)->world = world;
+    S(s)->committed = false;
+    return RT_OK;
+}
+
+int rt_scene_set_camera(rt_scene *s, const double lookfrom[3], const double lookat[3], const double vup[3],
+                        double vfov_degrees, double aspect, double aperture, double focus_dist, double time0,
+                        double time1, const double background[3])
+{
+    if (!s || !lookfrom || !lookat || !vup || !background) return fail(RT_ERR_INVALID, "rt_scene_set_camera: null argument");
+    // Camera.h:47-72
+    CameraRec c{};
+    D3 from = mk(lookfrom[0], lookfrom[1], lookfrom[2]), at = mk(lookat[0], lookat[1], lookat[2]);
+    D3 up = mk(vup[0], vup[1], vup[2]);
+    double theta = vfov_degrees * 3.14159265358979323846 / 180.0;
+    double half_h = std::tan(theta / 2.0);
+    double half_w = aspect * half_h;
+    D3 w = normalize(sub(from, at));
+    D3 u = normalize(cross(up, w));
+    D3 v = cross(w, u);
+    D3 llc = sub(sub(sub(from, scale(half_w * focus_dist, u)), scale(half_h * focus_dist, v)), scale(focus_dist, w));
+    D3 horiz = scale(2.0 * half_w * focus_dist, u);
+    D3 vert = scale(2.0 * half_h * focus_dist, v);
+    auto put = [](double *dst, D3 a) { dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; };
+    put(c.bg, mk(background[0], background[1], background[2]));
+    put(c.origin, from);
+    put(c.llc, llc);
+    put(c.horizontal, horiz);
+    put(c.vertical, vert);
+    put(c.u, u);
+    put(c.v, v);
+    put(c.w, w);
+    c.lens_radius = aperture / 2.0;
+    c.time0 = time0;
+    c.time1 = time1;
+    S(s)->camera = c;
+    S(s)->has_camera = true;
+    return RT_OK;
+}
+
+int rt_scene_commit(rt_scene *s)
+{
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: null scene");
+    return flatten_scene(*S(s));
+}
+
+int rt_scene_get_info(rt_scene *s, rt_scene_info *out)
+{
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_info: null argument");
+    if (!S(s)->committed) return fail(RT_ERR_STATE, "rt_scene_get_info: scene not committed");
+    const FlatScene &f = S(s)->flat;
+    std::memset(out, 0, sizeof *out);
+    out->world_kind = f.world_kind;
+    out->n_leaves = (uint32_t)f.world_items.size();
+    out->n_nodes = (uint32_t)f.nodes.size();
+    out->n_spheres = (uint32_t)f.spheres.size();
+    out->n_moving_spheres = (uint32_t)f.mspheres.size();
+    out->n_quads = (uint32_t)f.quads.size();
+    out->n_objects = (uint32_t)f.objects.size();
+    out->n_xforms = (uint32_t)f.xforms.size();
+    out->n_media = (uint32_t)f.media.size();
+    out->n_materials = (uint32_t)f.materials.size();
+    out->n_textures = (uint32_t)f.textures.size();
+    out->n_perlin = (uint32_t)f.perlin.size();
+    out->n_images = (uint32_t)f.images.size();
+    out->table_bytes = (uint32_t)(f.nodes.size() * sizeof(BvhNodeRec) + f.spheres.size() * sizeof(SphereGeom) +
+                                  f.mspheres.size() * sizeof(MSphereGeom) + f.quads.size() * sizeof(QuadGeom) +
+                                  f.objects.size() * sizeof(ObjectRec) + f.xforms.size() * sizeof(Xform) +
+                                  f.materials.size() * sizeof(MaterialRec));
+    out->image_bytes = (uint32_t)f.image_bytes.size();
+    return RT_OK;
+}
+
+int rt_scene_dump_leaves(rt_scene *s, int max_leaves, int *kind_out, double *box_out)
+{
+    if (!s || !S(s)->committed) return -fail(RT_ERR_STATE, "rt_scene_dump_leaves: scene not committed");
+    const FlatScene &f = S(s)->flat;
+    int n = (int)f.world_items.size();
+    for (int k = 0; k < n && k < max_leaves; k++) {
+        if (kind_out) kind_out[k] = (int)(f.world_items[k] >> kRefShift);
+        if (box_out)
+            for (int a = 0; a < 3; a++) {
+                box_out[6 * k + 2 * a] = f.leaf_boxes[k].lo[a];
+                box_out[6 * k + 2 * a + 1] = f.leaf_boxes[k].hi[a];
+            }
+    }
+    return n;
+}
+int rt_scene_dump_nodes(rt_scene *s, int max_nodes, double *box_out, uint32_t *abe_out)
+{
+    if (!s || !S(s)->committed) return -fail(RT_ERR_STATE, "rt_scene_dump_nodes: scene not committed");
+    const FlatScene &f = S(s)->flat;
+    int n = (int)f.nodes.size();
+    for (int k = 0; k < n && k < max_nodes; k++) {
+        const BvhNodeRec &r = f.nodes[k];
+        if (box_out) {
+            double *b = box_out + 6 * k;
+            b[0] = r.xlo; b[1] = r.xhi; b[2] = r.ylo; b[3] = r.yhi; b[4] = r.zlo; b[5] = r.zhi;
+        }
+        if (abe_out) {
+            abe_out[3 * k] = r.a;
+            abe_out[3 * k + 1] = r.b;
+            abe_out[3 * k + 2] = r.escape;
+        }
+    }
+    return n;
+}
+int rt_scene_dump_camera(rt_scene *s, double out27[27])
+{
+    if (!s || !S(s)->has_camera || !out27) return fail(RT_ERR_STATE, "rt_scene_dump_camera: no camera");
+    const CameraRec &c = S(s)->camera;
+    const double *vs[8] = {c.bg, c.origin, c.llc, c.horizontal, c.vertical, c.u, c.v, c.w};
+    for (int k = 0; k < 8; k++) std::memcpy(out27 + 3 * k, vs[k], 3 * sizeof(double));
+    out27[24] = c.lens_radius;
+    out27[25] = c.time0;
+    out27[26] = c.time1;
+    return RT_OK;
+}
+
+int rt_stripe_rows(int height, int stripe_rows, int rank, int world_size, int *rows_out, int max_rows)
+{
+    if (height < 0 || stripe_rows <= 0 || world_size <= 0 || rank < 0 || rank >= world_size) return -1;
+    int n = 0;
+    for (int j = 0; j < height; j++)
+        if ((j / stripe_rows) % world_size == rank) {
+            if (rows_out && n < max_rows) rows_out[n] = j;
+            n++;
+        }
+    return n;
+}
+
+int rt_deinterleave(const double *gathered, int width, int height, int stripe_rows, int world_size,
+                    size_t rank_stride_doubles, double *frame_full)
+{
+    if (!gathered || !frame_full || width <= 0 || height <= 0 || stripe_rows <= 0 || world_size <= 0)
+        return fail(RT_ERR_INVALID, "rt_deinterleave: bad arguments");
+    std::vector<size_t> next(world_size, 0);
+    for (int j = 0; j < height; j++) {
+        int r = (j / stripe_rows) % world_size;
+        const double *src = gathered + (size_t)r * rank_stride_doubles + next[r] * (size_t)width * 3;
+        std::memcpy(frame_full + (size_t)j * width * 3, src, sizeof(double) * (size_t)width * 3);
+        next[r]++;
+    }
+    return RT_OK;
+}
+
+int rt_write_ppm(const char *path, const double *frame, int width, int height)
+{
+    if (!path || !frame || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_write_ppm: bad arguments");
+    FILE *fp = std::fopen(path, "w");
+    if (!fp) return fail(RT_ERR_INVALID, std::string("rt_write_ppm: cannot open ") + path);
+    // R/kernel.cu:696-721: text P3, top row (j = H-1) first, clamp to [0, 0.999], int(256 * c)
+    std::string buf;
+    buf.reserve((size_t)width * 12 * 64);
+    std::fprintf(fp, "P3\n%d %d\n255\n", width, height);
+    char line[64];
+    for (int j = height - 1; j >= 0; j--) {
+        buf.clear();
+        for (int i = 0; i < width; i++) {
+            const double *c = frame + ((size_t)j * width + i) * 3;
+            int q[3];
+            for (int k = 0; k < 3; k++) {
+                double x = c[k] < 0.0 ? 0.0 : (c[k] > 0.999 ? 0.999 : c[k]);
+                q[k] = (int)(256.0 * x);
+            }
+            int n = std::snprintf(line, sizeof line, "%d %d %d\n", q[0], q[1], q[2]);
+            buf.append(line, (size_t)n);
+        }
+        std::fwrite(buf.data(), 1, buf.size(), fp);
+    }
+    std::fclose(fp);
+    return RT_OK;
+}
+
+} // extern "C"

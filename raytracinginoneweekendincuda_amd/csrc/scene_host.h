@@ -1,0 +1,118 @@
+// scene_host.h -- host-side object graph behind the construction API, and its flattened form.
+// Internal to librtow_hip.so.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "flat_scene.h"
+#include "rng.h"
+
+namespace rtow {
+
+struct D3 {
+    double x, y, z;
+};
+
+struct Box {  // R/AABB.h:16-22: three closed intervals
+    double lo[3], hi[3];
+};
+
+enum class HKind : uint8_t { Sphere, MovingSphere, Quad, Translate, RotateY, List, Bvh, Medium };
+
+struct HostHittable {
+    HKind kind;
+    Box box;
+    uint32_t material = 0;             // handle (1-based) for primitives; phase function for media
+    D3 c0{}, c1{};                     // sphere centre(s)
+    double t0 = 0, t1 = 0, radius = 0;
+    D3 q{}, u{}, v{}, w{}, normal{};   // quad
+    double plane_d = 0;
+    uint32_t child = 0;                // instance / medium: wrapped hittable handle
+    D3 offset{};
+    double sin_t = 0, cos_t = 0;
+    std::vector<uint32_t> items;       // list children / bvh leaves (in sorted order, after build)
+    double neg_inv_density = 0;
+    // bvh topology (built at construction): nodes in preorder
+    struct TreeNode {
+        Box box;
+        int left, right;               // child tree-node indices, or -1
+        uint32_t leaf_a, leaf_b;       // hittable handles when bottom node, else 0
+    };
+    std::vector<TreeNode> tree;
+};
+
+struct HostMaterial {
+    uint32_t kind;
+    uint32_t texture = 0;  // handle (1-based) or 0
+    D3 albedo{};
+    double p = 0;
+};
+
+struct HostTexture {
+    uint32_t kind;
+    D3 color{};
+    double s = 0;
+    uint32_t a = 0, b = 0;  // checker: even/odd handles; image: image index; noise: perlin index
+};
+
+struct FlatScene {
+    std::vector<SphereGeom> spheres;
+    std::vector<SphereAux> sphere_aux;
+    std::vector<MSphereGeom> mspheres;
+    std::vector<SphereAux> msphere_aux;
+    std::vector<QuadGeom> quads;
+    std::vector<uint32_t> quad_mat;
+    std::vector<ObjectRec> objects;
+    std::vector<uint32_t> items;
+    std::vector<Xform> xforms;
+    std::vector<MediumRec> media;
+    std::vector<BvhNodeRec> nodes;
+    std::vector<uint32_t> world_items;   // leaf refs in final order (both world kinds)
+    std::vector<Box> leaf_boxes;         // introspection
+    std::vector<MaterialRec> materials;
+    std::vector<TextureRec> textures;
+    std::vector<ImageRec> images;
+    std::vector<unsigned char> image_bytes;
+    std::vector<PerlinRec> perlin;
+    uint32_t world_kind = WORLD_BVH;
+    uint32_t flags = 0;
+};
+
+struct DeviceTables;  // device_scene.cpp
+
+struct SceneImpl {
+    std::vector<HostHittable> hittables;  // handle = index + 1
+    std::vector<HostMaterial> materials;
+    std::vector<HostTexture> textures;
+    std::vector<ImageRec> images;
+    std::vector<unsigned char> image_bytes;
+    std::vector<PerlinRec> perlin;
+    uint32_t world = 0;
+    bool has_camera = false;
+    CameraRec camera{};
+    bool committed = false;
+    FlatScene flat;
+    std::vector<DeviceTables *> device;  // one per device ordinal, lazily
+
+    ~SceneImpl();
+};
+
+struct RngImpl {
+    Xorwow state;
+};
+
+// error plumbing (thread-local message)
+void set_error(const std::string &msg);
+int fail(int status, const std::string &msg);
+
+// host jump table for curand_init's sequence skip (built once, on first use)
+const uint32_t *host_jump_table();
+
+// flattening (scene_builder.cpp)
+int flatten_scene(SceneImpl &s);
+
+// device side (device_scene.cpp)
+void release_device_tables(DeviceTables *t);
+
+} // namespace rtow

@@ -1,0 +1,81 @@
+"""The C-ABI library loads and exports exactly what include/rtow.h declares (no compute calls)."""
+import os
+import re
+
+import raytracinginoneweekendincuda_amd as rt
+from raytracinginoneweekendincuda_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rtow.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"RTOW_API[^;(]*?\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 50
+    L = rt.lib()
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in rtow.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "python binding table and rtow.h disagree"
+
+
+def test_version_and_error_strings():
+    assert b"gfx950" in rt.lib().rt_version()
+    s = rt.Scene()
+    try:
+        s.Sphere((0, 0, 0), 1.0, 12345)  # invalid material handle
+    except rt.RtowError as e:
+        assert "material" in str(e)
+    else:
+        raise AssertionError("invalid handle accepted")
+
+
+def test_commit_requires_world_and_camera():
+    s = rt.Scene()
+    m = s.Lambertian((0.5, 0.5, 0.5))
+    sp = s.Sphere((0, 0, -1), 0.5, m)
+    try:
+        s.Commit()
+    except rt.RtowError as e:
+        assert "world" in str(e)
+    else:
+        raise AssertionError
+    s.SetWorld(s.HittableList([sp]))
+    try:
+        s.Commit()
+    except rt.RtowError as e:
+        assert "camera" in str(e)
+    else:
+        raise AssertionError
+
+
+def test_unsupported_nesting_is_reported():
+    s = rt.Scene()
+    m = s.Lambertian((0.5, 0.5, 0.5))
+    inner = s.ConstantMedium(s.Sphere((0, 0, 0), 1.0, m), 0.1, (1, 1, 1))
+    outer = s.ConstantMedium(inner, 0.1, (1, 1, 1))
+    s.SetWorld(s.HittableList([outer]))
+    s.Camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0)
+    try:
+        s.Commit()
+    except rt.RtowError as e:
+        assert "unsupported nesting" in str(e)
+    else:
+        raise AssertionError
+
+
+def test_render_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        return
+    s = rt.builtin_scene(10, 0, 16, 8)
+    try:
+        s.render(16, 8, 1)
+    except rt.RtowError as e:
+        assert "no HIP device" in str(e) or "HIP error" in str(e)
+    else:
+        raise AssertionError("render succeeded without a GPU: a CPU fallback must not exist")

@@ -166,6 +166,9 @@ RTOW_API void rt_film_destroy(rt_film *film);
 /* Device pointer of this rank's compact framebuffer: rows_owned x width x 3 doubles (sqrt-gamma applied, like
  * frameBuffer[] at R/kernel.cu:150-153), rows in ascending j. */
 RTOW_API void *rt_film_device_pixels(rt_film *film);
+/* Render into caller-owned device memory instead (e.g. a torch tensor that RCCL will gather from); must hold
+ * rt_film_pixel_bytes() bytes on the film's device.  NULL restores the film's own buffer. */
+RTOW_API int rt_film_bind_pixels(rt_film *film, void *device_pixels);
 RTOW_API size_t rt_film_pixel_bytes(rt_film *film);
 
 /* Upload the committed scene to a device (idempotent per device). */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "rt_film_destroy": (None, [P]),
     "rt_film_device_pixels": (P, [P]),
     "rt_film_pixel_bytes": (C.c_size_t, [P]),
+    "rt_film_bind_pixels": (I, [P, P]),
     "rt_scene_upload": (I, [P, I]),
     "rt_render_launch": (I, [P, P, C.POINTER(RenderParams)]),
     "rt_render_finish": (I, [P, P, C.POINTER(RenderStats)]),

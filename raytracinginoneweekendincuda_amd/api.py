@@ -258,6 +258,14 @@ class Film:
     def device_pixels(self):
         return lib().rt_film_device_pixels(self._p), lib().rt_film_pixel_bytes(self._p)
 
+    def bind_pixels(self, device_ptr):
+        """Render into caller-owned device memory (a torch tensor's data_ptr()) of pixel_bytes bytes."""
+        _check(lib().rt_film_bind_pixels(self._p, device_ptr))
+
+    @property
+    def pixel_bytes(self):
+        return lib().rt_film_pixel_bytes(self._p)
+
     def download(self):
         frame = np.zeros((self.height, self.width, 3), dtype=np.float64)
         _check(lib().rt_film_download(self._p, frame.ctypes.data_as(_lib.D3), self.width, self.height))

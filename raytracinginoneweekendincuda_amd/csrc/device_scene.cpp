@@ -93,7 +93,8 @@ struct FilmImpl {
     int width = 0, height = 0, stripe_rows = 8, rank = 0, world_size = 1;
     int rows_owned = 0;
     uint32_t n_pixels = 0;
-    double *pixels = nullptr;
+    double *pixels = nullptr;      // where the kernel writes (own_pixels or a bound external buffer)
+    double *own_pixels = nullptr;
     uint32_t *state = nullptr;
     unsigned long long *ray_counter = nullptr;
     hipStream_t own_stream = nullptr;
@@ -185,8 +186,9 @@ rt_film *rt_film_create(int device, int width, int height, int stripe_rows, int 
     f->rows_owned = rt_stripe_rows(height, stripe_rows, rank, world_size, nullptr, 0);
     f->n_pixels = (uint32_t)f->rows_owned * (uint32_t)width;
     size_t np = f->n_pixels ? f->n_pixels : 1;
-    hipError_t e = hipMalloc((void **)&f->pixels, np * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMemset(f->pixels, 0, np * 3 * sizeof(double));
+    hipError_t e = hipMalloc((void **)&f->own_pixels, np * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(f->own_pixels, 0, np * 3 * sizeof(double));
+    f->pixels = f->own_pixels;
     if (e == hipSuccess) e = hipMalloc((void **)&f->state, np * 6 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking);
@@ -204,7 +206,7 @@ void rt_film_destroy(rt_film *film)
     if (!film) return;
     FilmImpl *f = F(film);
     hipSetDevice(f->device);
-    if (f->pixels) hipFree(f->pixels);
+    if (f->own_pixels) hipFree(f->own_pixels);
     if (f->state) hipFree(f->state);
     if (f->ray_counter) hipFree(f->ray_counter);
     for (int k = 0; k < 3; k++)
@@ -215,6 +217,13 @@ void rt_film_destroy(rt_film *film)
 
 void *rt_film_device_pixels(rt_film *film) { return film ? F(film)->pixels : nullptr; }
 size_t rt_film_pixel_bytes(rt_film *film) { return film ? (size_t)F(film)->n_pixels * 3 * sizeof(double) : 0; }
+int rt_film_bind_pixels(rt_film *film, void *device_pixels)
+{
+    if (!film) return fail(RT_ERR_INVALID, "rt_film_bind_pixels: null film");
+    if (F(film)->in_flight) return fail(RT_ERR_STATE, "rt_film_bind_pixels: a render is in flight");
+    F(film)->pixels = device_pixels ? static_cast<double *>(device_pixels) : F(film)->own_pixels;
+    return RT_OK;
+}
 
 int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
 {
@@ -322,7 +331,7 @@ int rt_render(rt_scene *scene, const rt_render_params *params, double *frame, rt
     if (!scene || !params || !frame) return fail(RT_ERR_INVALID, "rt_render: null argument");
     rt_film *film = rt_film_create(params->device, params->width, params->height, params->stripe_rows > 0 ? params->stripe_rows : 8,
                                    params->rank, params->world_size > 0 ? params->world_size : 1);
-    if (!film) return RT_ERR_HIP;
+    if (!film) return std::strstr(rt_last_error(), "no HIP device") ? RT_ERR_NO_DEVICE : RT_ERR_HIP;
     rt_render_params p = *params;
     if (p.stripe_rows <= 0) p.stripe_rows = 8;
     if (p.world_size <= 0) p.world_size = 1;

@@ -143,9 +143,12 @@ typedef struct rt_render_params {
     int32_t device;               /* HIP device ordinal */
     int32_t flags;                /* RT_FLAG_* */
     void *stream;                 /* hipStream_t to launch on (NULL = the film's own stream) */
+    int32_t coop_threshold;       /* tuning: sphere-list waves with fewer live lanes scan cooperatively (0 = default) */
+    int32_t reserved;
 } rt_render_params;
 
 #define RT_FLAG_KEEP_RNG_STATE 1u  /* do not re-seed: continue from the film's saved per-pixel state (progressive) */
+#define RT_FLAG_FORCE_GENERAL 2u   /* tests: run the general kernel even where a specialised instantiation applies */
 
 typedef struct rt_render_stats {
     uint64_t samples;             /* pixels rendered by this rank x spp */
@@ -156,6 +159,8 @@ typedef struct rt_render_stats {
     uint32_t rows;                /* rows owned by this rank */
     uint32_t kernel_vgprs;
     uint32_t lds_bytes;
+    uint32_t kernel_kind;         /* which instantiation ran: world*4 + composite*2 + rich (world 0 bvh, 1 list, 2 sphere list) */
+    uint32_t reserved;
 } rt_render_stats;
 
 /* Rows owned by (rank, world_size) for a height: returns count, fills rows_out (ascending j) if non-NULL. */

@@ -11,6 +11,7 @@ class RenderParams(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32),
         ("seed", C.c_uint64), ("stripe_rows", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
         ("variant", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
+        ("coop_threshold", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -18,6 +19,7 @@ class RenderStats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("rays", C.c_uint64), ("seconds_seed", C.c_double), ("seconds_render", C.c_double),
         ("pixels", C.c_uint32), ("rows", C.c_uint32), ("kernel_vgprs", C.c_uint32), ("lds_bytes", C.c_uint32),
+        ("kernel_kind", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

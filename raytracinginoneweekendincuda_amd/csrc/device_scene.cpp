@@ -96,7 +96,8 @@ struct FilmImpl {
     double *pixels = nullptr;      // where the kernel writes (own_pixels or a bound external buffer)
     double *own_pixels = nullptr;
     uint32_t *state = nullptr;
-    unsigned long long *ray_counter = nullptr;
+    unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor
+    int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // begin, after seed, after render
@@ -104,6 +105,7 @@ struct FilmImpl {
     bool in_flight = false;
     uint64_t last_samples = 0;
     int last_variant = 0;
+    KernelInfo last_kernel{};
 };
 
 } // namespace rtow
@@ -148,11 +150,12 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.images, d.images);
     up(f.image_bytes, d.image_bytes);
     up(f.perlin, d.perlin);
+    std::vector<CameraRec> cam_host(1, s.camera);
+    up(cam_host, d.camera);
     if (rc != RT_OK) {
         release_device_tables(dt);
         return rc;
     }
-    d.camera = s.camera;
     d.world_kind = f.world_kind;
     d.n_world_items = (uint32_t)f.world_items.size();
     d.n_nodes = (uint32_t)f.nodes.size();
@@ -190,7 +193,12 @@ rt_film *rt_film_create(int device, int width, int height, int stripe_rows, int 
     if (e == hipSuccess) e = hipMemset(f->own_pixels, 0, np * 3 * sizeof(double));
     f->pixels = f->own_pixels;
     if (e == hipSuccess) e = hipMalloc((void **)&f->state, np * 6 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e == hipSuccess) f->num_cus = prop.multiProcessorCount;
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking);
     for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreate(&f->ev[k]);
     if (e != hipSuccess) {
@@ -240,7 +248,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : f.own_stream;
     const bool keep = (p->flags & RT_FLAG_KEEP_RNG_STATE) && f.seeded;
 
-    HIP_TRY(hipMemsetAsync(f.ray_counter, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(f.ev[0], stream));
     if (!keep) {
         SeedArgs sa{};
@@ -260,6 +268,9 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.pixels = f.pixels;
     ra.state = f.state;
     ra.ray_counter = f.ray_counter;
+    ra.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 1);
+    ra.coop_threshold = p->coop_threshold > 0 ? p->coop_threshold : 24;
+    ra.num_cus = f.num_cus;
     ra.n_pixels = f.n_pixels;
     ra.width = f.width;
     ra.height = f.height;
@@ -269,7 +280,9 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.stripe_rows = f.stripe_rows;
     ra.rank = f.rank;
     ra.world_size = f.world_size;
+    ra.force_general = (p->flags & RT_FLAG_FORCE_GENERAL) ? 1 : 0;
     const DeviceScene &ds = s.device[f.device]->scene;
+    HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
     HIP_TRY(p->variant ? launch_render_fast(ds, ra, stream) : launch_render_strict(ds, ra, stream));
     HIP_TRY(hipEventRecord(f.ev[2], stream));
     f.last_stream = stream;
@@ -301,10 +314,9 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         stats->seconds_render = ms_render * 1e-3;
         stats->pixels = f.n_pixels;
         stats->rows = (uint32_t)f.rows_owned;
-        int vg = 0, lds = 0;
-        HIP_TRY(f.last_variant ? kernel_attributes_fast(&vg, &lds) : kernel_attributes_strict(&vg, &lds));
-        stats->kernel_vgprs = (uint32_t)vg;
-        stats->lds_bytes = (uint32_t)lds;
+        stats->kernel_vgprs = (uint32_t)f.last_kernel.vgprs;
+        stats->lds_bytes = (uint32_t)f.last_kernel.lds_bytes;
+        stats->kernel_kind = (uint32_t)f.last_kernel.kind;
     }
     return RT_OK;
 }

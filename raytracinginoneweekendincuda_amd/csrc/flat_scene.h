@@ -93,7 +93,7 @@ struct DeviceScene {
     const ImageRec *images;
     const unsigned char *image_bytes;
     const PerlinRec *perlin;
-    CameraRec camera;
+    const CameraRec *camera;
     uint32_t world_kind;
     uint32_t n_world_items;
     uint32_t n_nodes;
@@ -104,6 +104,7 @@ struct DeviceScene {
 enum : uint32_t {
     SCENE_HAS_MEDIA = 1u,
     SCENE_LIST_ALL_SPHERES = 2u,  // WORLD_LIST whose leaves are spheres 0..n-1 in order (config C2 fast path)
+    SCENE_RICH_TEXTURES = 4u,     // some texture is an ImageTexture or NoiseTexture
 };
 
 } // namespace rtow

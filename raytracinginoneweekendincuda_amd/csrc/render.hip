@@ -6,9 +6,11 @@
 // and Texture::Value.  Not a translation: one lane owns one pixel and runs a flat
 // "one ray segment per iteration" loop with path regeneration (a lane whose path ends starts its
 // pixel's next sample in the same iteration), virtual dispatch is tag dispatch over the SoA tables
-// of flat_scene.h, the BVH is walked stacklessly through escape links, hit records are built once
-// per bounce from (t, primitive) instead of on every accepted candidate, and sphere UVs are computed
-// only when an image texture will read them.  Each of these is result-preserving: see DESIGN.md.
+// of flat_scene.h, the BVH is walked stacklessly through escape links with its nodes staged in LDS,
+// a list-of-spheres world is scanned with wave-uniform (scalar-path) primitive rows while the rare
+// sqrt/divide root work is deferred to a per-lane LDS queue, hit records are built once per bounce
+// from (t, primitive) instead of on every accepted candidate, and sphere UVs are computed only when
+// an image texture will read them.  Each of these is result-preserving: see DESIGN.md.
 //
 // This file is compiled twice: RT_STRICT=1 with -ffp-contract=off (no FMA; bit-comparable with the
 // CPU oracle) and RT_STRICT=0 with the default contraction (fast variant).
@@ -28,6 +30,19 @@
 namespace rtow {
 namespace {
 
+// Kernel specialisation.  One source, a few instantiations; the host picks by what the scene contains so
+// that a scene never pays registers or code for features it does not use:
+//   WORLD      0 = BvhNode world (threaded, nodes staged in LDS), 1 = HittableList world (uniform scan),
+//              2 = HittableList of static spheres only (config C2: scalar-fed discriminant scan + LDS queue)
+//   COMPOSITE  instances / boxes / lists / media may appear as leaves
+//   RICH       Perlin-noise or image textures may appear
+template <int WORLD_, bool COMPOSITE_, bool RICH_>
+struct Traits {
+    static constexpr int WORLD = WORLD_;
+    static constexpr bool COMPOSITE = COMPOSITE_;
+    static constexpr bool RICH = RICH_;
+};
+
 struct Vec {
     double x, y, z;
 };
@@ -45,6 +60,14 @@ struct Surface {
     double u, v;
     uint32_t mat;
     bool front;
+};
+
+// BVH nodes as the traversal sees them: SoA planes in LDS (or the global AoS table when they do not fit).
+struct NodeView {
+    const double *xlo, *xhi, *ylo, *yhi, *zlo, *zhi;  // LDS planes
+    const uint32_t *a, *b, *escape;
+    const BvhNodeRec *global;
+    bool in_lds;
 };
 
 #define DEV __device__ __forceinline__
@@ -75,6 +98,27 @@ DEV Vec load3(const double *p) { return mk(p[0], p[1], p[2]); }
 // ------------------------------------------------------------------------------------------------
 // primitive tests.  Each returns the accepted t exactly as the reference's Hit would set rec.T.
 // ------------------------------------------------------------------------------------------------
+// Root selection of R/Sphere.h:36-60 given b, disc (> 0) and a.  The second root is only evaluated when
+// the first is at or below tmin: if the first root is >= tmax so is the second (a > 0, s >= 0, and
+// division by a is monotone), so the reference's second test cannot pass there either.
+DEV bool sphere_roots(double b, double disc, double a, double tmin, double tmax, double &t_out)
+{
+    double s = sqrt(disc);
+    double t = (-b - s) / a;
+    if (t < tmax) {
+        if (t > tmin) {
+            t_out = t;
+            return true;
+        }
+        t = (-b + s) / a;
+        if (t < tmax && t > tmin) {
+            t_out = t;
+            return true;
+        }
+    }
+    return false;
+}
+
 // R/Sphere.h:28-60 (also MovingSphere.h:54-86): strict interval, disc > 0, first root then second.
 DEV bool sphere_test(Vec oc, Vec d, double a, double r2, double tmin, double tmax, double &t_out)
 {
@@ -86,17 +130,7 @@ DEV bool sphere_test(Vec oc, Vec d, double a, double r2, double tmin, double tma
         // -b - s < 0, and s = sqrt(b*b - a*c) <= |b| in fp64 because a*c > 0, so -b + s <= 0.  With
         // tmin >= 0 neither can pass `temp > tmin`; skipping the sqrt/divides changes nothing.
         if (tmin >= 0.0 && b > 0.0 && c > 0.0) return false;
-        double s = sqrt(disc);
-        double t = (-b - s) / a;
-        if (t < tmax && t > tmin) {
-            t_out = t;
-            return true;
-        }
-        t = (-b + s) / a;
-        if (t < tmax && t > tmin) {
-            t_out = t;
-            return true;
-        }
+        return sphere_roots(b, disc, a, tmin, tmax, t_out);
     }
     return false;
 }
@@ -124,7 +158,6 @@ DEV Vec msphere_center(const MSphereGeom &g, double tm)  // R/MovingSphere.h:51-
     return mk(g.c0x, g.c0y, g.c0z) + frac * mk(g.dcx, g.dcy, g.dcz);
 }
 
-// Test one primitive reference; on success updates closest/best.
 DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, double &t)
 {
     uint32_t idx = ref & kRefIndexMask;
@@ -261,9 +294,12 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     return true;
 }
 
+template <class T>
 DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng)
 {
-    if ((ref >> kRefShift) == REF_OBJECT) return object_test(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
+    if constexpr (T::COMPOSITE) {
+        if ((ref >> kRefShift) == REF_OBJECT) return object_test(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
+    }
     double t;
     if (!prim_test(sc, ref, r, a, tmin, tmax, t)) return false;
     best.t = t;
@@ -281,17 +317,18 @@ DEV bool is_medium_leaf(const DeviceScene &sc, uint32_t ref)
 // world traversal
 // ------------------------------------------------------------------------------------------------
 // Slab test, R/AABB.h:68-98, with 1/d hoisted out of the node loop (same value every time).
-DEV bool box_test(const BvhNodeRec &n, const Ray &r, Vec inv, double tmin, double tmax)
+DEV bool box_test(double xlo, double xhi, double ylo, double yhi, double zlo, double zhi, const Ray &r, Vec inv,
+                  double tmin, double tmax)
 {
-    double t0 = (n.xlo - r.o.x) * inv.x, t1 = (n.xhi - r.o.x) * inv.x;
+    double t0 = (xlo - r.o.x) * inv.x, t1 = (xhi - r.o.x) * inv.x;
     tmin = fmax(tmin, fmin(t0, t1));
     tmax = fmin(tmax, fmax(t0, t1));
-    t0 = (n.ylo - r.o.y) * inv.y;
-    t1 = (n.yhi - r.o.y) * inv.y;
+    t0 = (ylo - r.o.y) * inv.y;
+    t1 = (yhi - r.o.y) * inv.y;
     tmin = fmax(tmin, fmin(t0, t1));
     tmax = fmin(tmax, fmax(t0, t1));
-    t0 = (n.zlo - r.o.z) * inv.z;
-    t1 = (n.zhi - r.o.z) * inv.z;
+    t0 = (zlo - r.o.z) * inv.z;
+    t1 = (zhi - r.o.z) * inv.z;
     tmin = fmax(tmin, fmin(t0, t1));
     tmax = fmin(tmax, fmax(t0, t1));
     return tmax > tmin;
@@ -299,7 +336,8 @@ DEV bool box_test(const BvhNodeRec &n, const Ray &r, Vec inv, double tmin, doubl
 
 // Stackless walk in the reference's visiting order (R/BvhNode.h:101-158): a node's leaf children are
 // tested where the node is visited; "pop" is the escape link.
-DEV bool world_hit_bvh(const DeviceScene &sc, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng)
+template <class T>
+DEV bool world_hit_bvh(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng)
 {
     Vec inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     double a = dot(r.d, r.d);
@@ -307,20 +345,30 @@ DEV bool world_hit_bvh(const DeviceScene &sc, const Ray &r, double tmin, double 
     bool any = false;
     uint32_t n = 0;
     while (n != kNone) {
-        BvhNodeRec node = sc.nodes[n];
-        uint32_t next = node.escape;
-        if (box_test(node, r, inv, tmin, closest)) {
-            if ((node.a >> kRefShift) == REF_INNER) {
+        double xlo, xhi, ylo, yhi, zlo, zhi;
+        uint32_t na, nb, next;
+        if (nv.in_lds) {
+            xlo = nv.xlo[n]; xhi = nv.xhi[n]; ylo = nv.ylo[n]; yhi = nv.yhi[n]; zlo = nv.zlo[n]; zhi = nv.zhi[n];
+            na = nv.a[n]; nb = nv.b[n]; next = nv.escape[n];
+        } else {
+            BvhNodeRec node = nv.global[n];
+            xlo = node.xlo; xhi = node.xhi; ylo = node.ylo; yhi = node.yhi; zlo = node.zlo; zhi = node.zhi;
+            na = node.a; nb = node.b; next = node.escape;
+        }
+        if (box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, inv, tmin, closest)) {
+            if ((na >> kRefShift) == REF_INNER) {
                 next = n + 1;
             } else {
-                if (leaf_test(sc, node.a, r, a, tmin, closest, best, rng)) {
+                if (leaf_test<T>(sc, na, r, a, tmin, closest, best, rng)) {
                     any = true;
                     closest = best.t;
                 }
                 // span-1 nodes hold the same leaf twice (R/BvhNode.h:63-67).  Re-testing a surface with
                 // tmax = its own t changes nothing; a medium draws again, so only media are re-tested.
-                if (node.b != node.a || is_medium_leaf(sc, node.b)) {
-                    if (leaf_test(sc, node.b, r, a, tmin, closest, best, rng)) {
+                bool again = nb != na;
+                if constexpr (T::COMPOSITE) again = again || is_medium_leaf(sc, nb);
+                if (again) {
+                    if (leaf_test<T>(sc, nb, r, a, tmin, closest, best, rng)) {
                         any = true;
                         closest = best.t;
                     }
@@ -334,35 +382,171 @@ DEV bool world_hit_bvh(const DeviceScene &sc, const Ray &r, double tmin, double 
 
 // HittableList world (R/HittableList.h:39-57): the item index is wave-uniform, so the primitive rows
 // are fetched through the scalar path.
+template <class T>
 DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng)
 {
     double a = dot(r.d, r.d);
     double closest = tmax;
     bool any = false;
-    if (sc.flags & SCENE_LIST_ALL_SPHERES) {
-        const uint32_t n = sc.n_spheres;
-        for (uint32_t k = 0; k < n; k++) {
-            SphereGeom g = sc.spheres[k];
-            double t;
-            if (sphere_test(r.o - mk(g.cx, g.cy, g.cz), r.d, a, g.r2, tmin, closest, t)) {
-                any = true;
-                closest = t;
-                best.t = t;
-                best.ref = make_ref(REF_SPHERE, k);
-                best.obj = kNone;
-            }
-        }
-        return any;
-    }
     const uint32_t n = sc.n_world_items;
     for (uint32_t k = 0; k < n; k++) {
         uint32_t ref = sc.world_items[k];
-        if (leaf_test(sc, ref, r, a, tmin, closest, best, rng)) {
+        if (leaf_test<T>(sc, ref, r, a, tmin, closest, best, rng)) {
             any = true;
             closest = best.t;
         }
     }
     return any;
+}
+
+// HittableList of static spheres (config C2).  Two phases per ray, identical results to the sequential scan:
+//  1. convergent scan: every lane evaluates b, c, disc of sphere k (k wave-uniform: the sphere row comes
+//     through the scalar cache into SGPRs); a lane for which the reference could accept a root
+//     (disc > 0 and not "outside and behind") appends k to its own queue in LDS;
+//  2. each lane walks its own queue in ascending k and does the sqrt / divide root selection against its
+//     running closest-so-far -- the same order the reference's loop meets those spheres in.
+constexpr int kQueueCap = 12;   // entries per lane; the queue is drained whenever a lane could overflow
+constexpr int kScanUnroll = 4;
+
+DEV void drain_queue(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
+                     const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
+{
+    for (uint32_t s = 0; s < count; s++) {
+        uint32_t k = queue[s * 64u + lane];
+        SphereGeom g = spheres[k];
+        Vec oc = r.o - mk(g.cx, g.cy, g.cz);
+        double b = dot(oc, r.d);
+        double c = dot(oc, oc) - g.r2;
+        double disc = b * b - a * c;
+        double t;
+        if (sphere_roots(b, disc, a, tmin, closest, t)) {
+            closest = t;
+            best_k = k;
+        }
+    }
+    count = 0;
+}
+
+// Four spheres of the convergent scan: the four discriminant chains are independent straight-line code
+// (the scheduler interleaves them), then each lane queues the spheres for which a root could be accepted.
+DEV void scan_four(const SphereGeom &g0, const SphereGeom &g1, const SphereGeom &g2, const SphereGeom &g3, uint32_t k0,
+                   const Ray &r, double a, uint16_t *queue, uint32_t lane, uint32_t &count)
+{
+    const SphereGeom *g[4] = {&g0, &g1, &g2, &g3};
+    double b[4], c[4], disc[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        Vec oc = r.o - mk(g[u]->cx, g[u]->cy, g[u]->cz);
+        b[u] = dot(oc, r.d);
+        c[u] = dot(oc, oc) - g[u]->r2;
+        disc[u] = b[u] * b[u] - a * c[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (disc[u] > 0.0 && !(b[u] > 0.0 && c[u] > 0.0)) {  // tmin = 0.001 >= 0: see sphere_test
+            queue[count * 64u + lane] = (uint16_t)(k0 + u);
+            count++;
+        }
+    }
+}
+
+DEV void scan_one(const SphereGeom &g, uint32_t k, const Ray &r, double a, uint16_t *queue, uint32_t lane, uint32_t &count)
+{
+    Vec oc = r.o - mk(g.cx, g.cy, g.cz);
+    double b = dot(oc, r.d);
+    double c = dot(oc, oc) - g.r2;
+    double disc = b * b - a * c;
+    if (disc > 0.0 && !(b > 0.0 && c > 0.0)) {
+        queue[count * 64u + lane] = (uint16_t)k;
+        count++;
+    }
+}
+
+// Pixel-parallel scan: every live lane traces its own ray; sphere rows are wave-uniform (scalar path).
+DEV bool scan_uniform(const DeviceScene &sc, uint16_t *queue, uint32_t lane, const Ray &r, double tmin, double tmax, HitInfo &best)
+{
+    const SphereGeom *__restrict__ spheres = sc.spheres;
+    const uint32_t n = sc.n_spheres;
+    const uint32_t n4 = n & ~3u;
+    const double a = dot(r.d, r.d);
+    double closest = tmax;
+    uint32_t best_k = kNone, count = 0;
+    // groups of four rows, the next group's scalar loads in flight while this group is evaluated
+    SphereGeom g0{}, g1{}, g2{}, g3{};
+    if (n4) {
+        g0 = spheres[0]; g1 = spheres[1]; g2 = spheres[2]; g3 = spheres[3];
+    }
+    for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
+        const uint32_t kn = (k0 + 4 < n4) ? k0 + 4 : k0;  // last group re-reads itself (stays in bounds)
+        const SphereGeom h0 = spheres[kn], h1 = spheres[kn + 1], h2 = spheres[kn + 2], h3 = spheres[kn + 3];
+        scan_four(g0, g1, g2, g3, k0, r, a, queue, lane, count);
+        g0 = h0; g1 = h1; g2 = h2; g3 = h3;
+        if (__any(count > (uint32_t)(kQueueCap - kScanUnroll))) drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    }
+    for (uint32_t k = n4; k < n; k++) scan_one(spheres[k], k, r, a, queue, lane, count);
+    drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    if (best_k == kNone) return false;
+    best.t = closest;
+    best.ref = make_ref(REF_SPHERE, best_k);
+    best.obj = kNone;
+    return true;
+}
+
+DEV double bcast(double x, int src_lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Ray-cooperative scan for sparse waves: all 64 lanes work on ONE ray (lane `src`'s), lane l testing spheres
+// l, l+64, ...; then a wave-wide min over (t, index).  Same winner as the sequential scan: that scan returns
+// the smallest "first acceptable root" over all spheres with ties going to the lowest index, and a root that
+// would have been rejected only because of an earlier closer hit loses the min here as well.
+DEV void scan_cooperative(const DeviceScene &sc, uint32_t lane, unsigned long long todo, const Ray &ray, double tmin, double tmax,
+                          HitInfo &best, bool &hit)
+{
+    const SphereGeom *__restrict__ spheres = sc.spheres;
+    const uint32_t n = sc.n_spheres;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        Ray r;
+        r.o = mk(bcast(ray.o.x, src), bcast(ray.o.y, src), bcast(ray.o.z, src));
+        r.d = mk(bcast(ray.d.x, src), bcast(ray.d.y, src), bcast(ray.d.z, src));
+        const double a = dot(r.d, r.d);
+        double bt = tmax;
+        uint32_t bk = kNone;
+        for (uint32_t k = lane; k < n; k += 64u) {
+            SphereGeom g = spheres[k];
+            Vec oc = r.o - mk(g.cx, g.cy, g.cz);
+            double b = dot(oc, r.d);
+            double c = dot(oc, oc) - g.r2;
+            double disc = b * b - a * c;
+            if (disc > 0.0 && !(b > 0.0 && c > 0.0)) {
+                double t;
+                if (sphere_roots(b, disc, a, tmin, bt, t)) {
+                    bt = t;
+                    bk = k;
+                }
+            }
+        }
+        // wave min over (t, k); lanes without a hit carry (tmax, kNone) and lose every comparison
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            double ot = __shfl_xor(bt, off, 64);
+            uint32_t ok = (uint32_t)__shfl_xor((int)bk, off, 64);
+            bool take = (ot < bt) || (ot == bt && ok < bk);
+            bt = take ? ot : bt;
+            bk = take ? ok : bk;
+        }
+        if ((int)lane == src) {
+            hit = bk != kNone;
+            best.t = bt;
+            best.ref = make_ref(REF_SPHERE, bk);
+            best.obj = kNone;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -383,40 +567,47 @@ DEV void face(Surface &s, const Ray &r, Vec outward)  // R/Hittable.h:26-30
     s.n = s.front ? outward : -outward;
 }
 
+template <class T>
 DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
 {
     Surface s;
     s.u = 0.0;
     s.v = 0.0;
     uint32_t tag = h.ref >> kRefShift, idx = h.ref & kRefIndexMask;
-    if (tag == REF_MEDIUM) {  // R/ConstantMedium.h:86-91
-        s.p = at(r, h.t);
-        s.n = mk(1, 0, 0);
-        s.front = true;
-        s.mat = sc.media[idx].phase_mat;
-        return s;
+    if constexpr (T::COMPOSITE) {
+        if (tag == REF_MEDIUM) {  // R/ConstantMedium.h:86-91
+            s.p = at(r, h.t);
+            s.n = mk(1, 0, 0);
+            s.front = true;
+            s.mat = sc.media[idx].phase_mat;
+            return s;
+        }
     }
-    ObjectRec o;
+    ObjectRec o{};
     Ray lr = r;
-    if (h.obj != kNone) {
-        o = sc.objects[h.obj];
-        lr = to_object_space(sc, o, r);
+    if constexpr (T::COMPOSITE) {
+        if (h.obj != kNone) {
+            o = sc.objects[h.obj];
+            lr = to_object_space(sc, o, r);
+        }
     }
     s.p = at(lr, h.t);
-    if (tag == REF_QUAD) {  // R/Quad.h:86-96
+    if (T::WORLD != 2 && tag == REF_QUAD) {  // R/Quad.h:86-96
         QuadGeom q = sc.quads[idx];
         s.mat = sc.quad_mat[idx];
         face(s, lr, mk(q.nx, q.ny, q.nz));
-        if (sc.materials[s.mat].needs_uv) {
-            Vec ph = s.p - mk(q.qx, q.qy, q.qz);
-            Vec w = mk(q.wx, q.wy, q.wz);
-            s.u = dot(w, cross(ph, mk(q.vx, q.vy, q.vz)));
-            s.v = dot(w, cross(mk(q.ux, q.uy, q.uz), ph));
+        if constexpr (T::RICH) {
+            if (sc.materials[s.mat].needs_uv) {
+                Vec ph = s.p - mk(q.qx, q.qy, q.qz);
+                Vec w = mk(q.wx, q.wy, q.wz);
+                s.u = dot(w, cross(ph, mk(q.vx, q.vy, q.vz)));
+                s.v = dot(w, cross(mk(q.ux, q.uy, q.uz), ph));
+            }
         }
     } else {  // R/Sphere.h:40-46
         Vec c;
         SphereAux aux;
-        if (tag == REF_SPHERE) {
+        if (T::WORLD == 2 || tag == REF_SPHERE) {
             SphereGeom g = sc.spheres[idx];
             c = mk(g.cx, g.cy, g.cz);
             aux = sc.sphere_aux[idx];
@@ -427,17 +618,21 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
         Vec on = aux.inv_r * (s.p - c);
         face(s, lr, on);
         s.mat = aux.mat;
-        if (sc.materials[s.mat].needs_uv) sphere_uv(on, s.u, s.v);
+        if constexpr (T::RICH) {
+            if (sc.materials[s.mat].needs_uv) sphere_uv(on, s.u, s.v);
+        }
     }
-    if (h.obj != kNone) {  // back to world space, innermost transform first (R/Instance.h:53,137-147)
-        for (uint32_t k = o.xf_count; k-- > 0;) {
-            Xform x = sc.xforms[o.xf_first + k];
-            if (x.kind == XF_TRANSLATE) {
-                s.p = s.p + mk(x.a, x.b, x.c);
-            } else {
-                double st = x.a, ct = x.b;
-                s.p = mk((ct * s.p.x) + (st * s.p.z), s.p.y, (-st * s.p.x) + (ct * s.p.z));
-                s.n = mk((ct * s.n.x) + (st * s.n.z), s.n.y, (-st * s.n.x) + (ct * s.n.z));
+    if constexpr (T::COMPOSITE) {
+        if (h.obj != kNone) {  // back to world space, innermost transform first (R/Instance.h:53,137-147)
+            for (uint32_t k = o.xf_count; k-- > 0;) {
+                Xform x = sc.xforms[o.xf_first + k];
+                if (x.kind == XF_TRANSLATE) {
+                    s.p = s.p + mk(x.a, x.b, x.c);
+                } else {
+                    double st = x.a, ct = x.b;
+                    s.p = mk((ct * s.p.x) + (st * s.p.z), s.p.y, (-st * s.p.x) + (ct * s.p.z));
+                    s.n = mk((ct * s.n.x) + (st * s.n.z), s.n.y, (-st * s.n.x) + (ct * s.n.z));
+                }
             }
         }
     }
@@ -447,7 +642,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
 // ------------------------------------------------------------------------------------------------
 // textures and materials
 // ------------------------------------------------------------------------------------------------
-DEV double perlin_noise(const PerlinRec &pn, Vec p)  // R/Perlin.h:38-60,120-139
+__device__ __noinline__ double perlin_noise(const PerlinRec *pn, Vec p)  // R/Perlin.h:38-60,120-139
 {
     double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
     double u = p.x - fx, v = p.y - fy, w = p.z - fz;
@@ -460,15 +655,15 @@ DEV double perlin_noise(const PerlinRec &pn, Vec p)  // R/Perlin.h:38-60,120-139
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                int idx = pn.perm_x[(i + a) & 255] ^ pn.perm_y[(j + b) & 255] ^ pn.perm_z[(k + c) & 255];
-                Vec g = mk(pn.vec[idx][0], pn.vec[idx][1], pn.vec[idx][2]);
+                int idx = pn->perm_x[(i + a) & 255] ^ pn->perm_y[(j + b) & 255] ^ pn->perm_z[(k + c) & 255];
+                Vec g = mk(pn->vec[idx][0], pn->vec[idx][1], pn->vec[idx][2]);
                 Vec wv = mk(u - a, v - b, w - c);
                 accum += (a * uu + (1 - a) * (1 - uu)) * (b * vv + (1 - b) * (1 - vv)) * (c * ww + (1 - c) * (1 - ww)) * dot(g, wv);
             }
     return accum;
 }
 
-DEV double perlin_turb(const PerlinRec &pn, Vec p, int depth)  // R/Perlin.h:63-78
+DEV double perlin_turb(const PerlinRec *pn, Vec p, int depth)  // R/Perlin.h:63-78
 {
     double accum = 0.0, weight = 1.0;
     for (int i = 0; i < depth; i++) {
@@ -479,6 +674,7 @@ DEV double perlin_turb(const PerlinRec &pn, Vec p, int depth)  // R/Perlin.h:63-
     return fabs(accum);
 }
 
+template <class T>
 DEV Vec texture_value(const DeviceScene &sc, uint32_t ti, double u, double v, Vec p)
 {
     TextureRec t = sc.textures[ti];
@@ -487,23 +683,26 @@ DEV Vec texture_value(const DeviceScene &sc, uint32_t ti, double u, double v, Ve
         bool even = ((xi + yi + zi) % 2) == 0;
         t = sc.textures[even ? t.a : t.b_];
     }
-    if (t.kind == TEX_SOLID) return mk(t.r, t.g, t.b);
-    if (t.kind == TEX_IMAGE) {  // R/Texture.h:110-133
-        ImageRec im = sc.images[t.a];
-        if (im.height <= 0) return mk(0.0, 1.0, 1.0);
-        u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
-        v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
-        v = 1.0 - v;
-        int i = (int)(u * im.width), j = (int)(v * im.height);
-        if (i >= im.width) i = im.width - 1;
-        if (j >= im.height) j = im.height - 1;
-        const unsigned char *px = sc.image_bytes + im.offset + ((size_t)j * im.width + i) * 3;
-        double cs = 1.0 / 255.0;
-        return mk(cs * px[0], cs * px[1], cs * px[2]);
+    if constexpr (T::RICH) {
+        if (t.kind == TEX_IMAGE) {  // R/Texture.h:110-133
+            ImageRec im = sc.images[t.a];
+            if (im.height <= 0) return mk(0.0, 1.0, 1.0);
+            u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            v = 1.0 - v;
+            int i = (int)(u * im.width), j = (int)(v * im.height);
+            if (i >= im.width) i = im.width - 1;
+            if (j >= im.height) j = im.height - 1;
+            const unsigned char *px = sc.image_bytes + im.offset + ((size_t)j * im.width + i) * 3;
+            double cs = 1.0 / 255.0;
+            return mk(cs * px[0], cs * px[1], cs * px[2]);
+        }
+        if (t.kind == TEX_NOISE) {  // R/Texture.h:159-165: marble
+            double sv = 1.0 + sin(t.s * p.z + 10.0 * perlin_turb(sc.perlin + t.a, p, 7));
+            return sv * mk(0.5, 0.5, 0.5);
+        }
     }
-    // R/Texture.h:159-165: marble
-    double sv = 1.0 + sin(t.s * p.z + 10.0 * perlin_turb(sc.perlin[t.a], p, 7));
-    return sv * mk(0.5, 0.5, 0.5);
+    return mk(t.r, t.g, t.b);  // TEX_SOLID, R/Texture.h:48-51
 }
 
 DEV Vec random_in_unit_sphere(Xorwow &rng)  // R/Material.h:14-24
@@ -519,6 +718,7 @@ DEV Vec random_in_unit_sphere(Xorwow &rng)  // R/Material.h:14-24
 }
 
 // Emitted + Scatter (R/kernel.cu:82-94).  Returns false when the path ends here.
+template <class T>
 DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughput, Vec &accumulated, Xorwow &rng)
 {
     MaterialRec m = sc.materials[s.mat];
@@ -528,13 +728,13 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
     out.tm = ray.tm;
     switch (m.kind) {
     case MAT_DIFFUSE_LIGHT:  // R/Material.h:114-127: emits on both sides, never scatters
-        accumulated = accumulated + throughput * texture_value(sc, m.tex, s.u, s.v, s.p);
+        accumulated = accumulated + throughput * texture_value<T>(sc, m.tex, s.u, s.v, s.p);
         return false;
     case MAT_LAMBERTIAN: {  // R/Material.h:67-82
         Vec dir = s.n + random_in_unit_sphere(rng);
         if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = s.n;
         out.d = dir;
-        atten = texture_value(sc, m.tex, s.u, s.v, s.p);
+        atten = texture_value<T>(sc, m.tex, s.u, s.v, s.p);
         break;
     }
     case MAT_METAL: {  // R/Metal.h:18-30
@@ -562,7 +762,7 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
     }
     default: {  // MAT_ISOTROPIC, R/Material.h:152-163
         out.d = unit(random_in_unit_sphere(rng));
-        atten = texture_value(sc, m.tex, s.u, s.v, s.p);
+        atten = texture_value<T>(sc, m.tex, s.u, s.v, s.p);
         break;
     }
     }
@@ -572,7 +772,7 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
 }
 
 // Camera::GetRay (R/Camera.h:76-85) behind the pixel jitter of Render (R/kernel.cu:140-142).
-DEV Ray camera_ray(const CameraRec &cam, int i, int j, int width, int height, Xorwow &rng)
+DEV Ray camera_ray(const CameraRec *__restrict__ cam, int i, int j, int width, int height, Xorwow &rng)
 {
     double u = (double)((float)i + xorwow_uniform(rng)) / (double)width;   // int + float adds in fp32
     double v = (double)((float)j + xorwow_uniform(rng)) / (double)height;
@@ -582,14 +782,14 @@ DEV Ray camera_ray(const CameraRec &cam, int i, int j, int width, int height, Xo
         double b = (double)xorwow_uniform(rng);
         p = 2.0 * mk(a, b, 0.0) - mk(1.0, 1.0, 0.0);
     } while (dot(p, p) >= 1.0);
-    Vec rd = cam.lens_radius * p;
-    Vec cu = load3(cam.u), cv = load3(cam.v);
+    Vec rd = cam->lens_radius * p;
+    Vec cu = load3(cam->u), cv = load3(cam->v);
     Vec offset = rd.x * cu + rd.y * cv;
-    double tm = cam.time0 + (double)xorwow_uniform(rng) * (cam.time1 - cam.time0);
-    Vec origin = load3(cam.origin);
+    double tm = cam->time0 + (double)xorwow_uniform(rng) * (cam->time1 - cam->time0);
+    Vec origin = load3(cam->origin);
     Ray r;
     r.o = origin + offset;
-    r.d = load3(cam.llc) + u * load3(cam.horizontal) + v * load3(cam.vertical) - origin - offset;
+    r.d = load3(cam->llc) + u * load3(cam->horizontal) + v * load3(cam->vertical) - origin - offset;
     r.tm = tm;
     return r;
 }
@@ -623,87 +823,152 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a)
     a.state[5 * (size_t)a.n_pixels + local] = s.v4;
 }
 
-template <int STRICT>
+extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+template <int STRICT, class T>
 __global__ __launch_bounds__(256) void render_kernel(DeviceScene sc, RenderArgs a)
 {
-    // one wave = one 8x8 pixel tile of this rank's compact image
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t tiles_x = ((uint32_t)a.width + 7u) >> 3;
-    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-    const int i = (int)(tx * 8u + (lane & 7u));
-    const int lr = (int)(ty * 8u + (lane >> 3));
-    bool active = i < a.width && lr < a.rows_owned && a.spp > 0;
-    const int j = owned_row(lr, a.stripe_rows, a.rank, a.world_size);
-    const size_t local = (size_t)lr * (size_t)a.width + (size_t)i;
-
-    Xorwow rng{0, 0, 0, 0, 0, 0};
-    if (active) {
-        rng.d = a.state[0 * (size_t)a.n_pixels + local];
-        rng.v0 = a.state[1 * (size_t)a.n_pixels + local];
-        rng.v1 = a.state[2 * (size_t)a.n_pixels + local];
-        rng.v2 = a.state[3 * (size_t)a.n_pixels + local];
-        rng.v3 = a.state[4 * (size_t)a.n_pixels + local];
-        rng.v4 = a.state[5 * (size_t)a.n_pixels + local];
+    // ---- chip-resident working set ----
+    NodeView nv{};
+    uint16_t *queue = nullptr;
+    if constexpr (T::WORLD == 0) {
+        // BVH nodes as SoA planes in LDS: lanes of a wave sit at different nodes, and 8-byte planes spread
+        // those reads over the banks (an AoS 64-byte node would put every lane on the same 4 banks).
+        nv.global = sc.nodes;
+        nv.in_lds = a.lds_nodes != 0;
+        if (nv.in_lds) {
+            const uint32_t n = sc.n_nodes;
+            double *planes = reinterpret_cast<double *>(lds_raw);
+            uint32_t *words = reinterpret_cast<uint32_t *>(planes + 6 * (size_t)n);
+            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+                BvhNodeRec node = sc.nodes[k];
+                planes[0 * n + k] = node.xlo; planes[1 * n + k] = node.xhi;
+                planes[2 * n + k] = node.ylo; planes[3 * n + k] = node.yhi;
+                planes[4 * n + k] = node.zlo; planes[5 * n + k] = node.zhi;
+                words[0 * n + k] = node.a; words[1 * n + k] = node.b; words[2 * n + k] = node.escape;
+            }
+            nv.xlo = planes; nv.xhi = planes + n; nv.ylo = planes + 2 * (size_t)n; nv.yhi = planes + 3 * (size_t)n;
+            nv.zlo = planes + 4 * (size_t)n; nv.zhi = planes + 5 * (size_t)n;
+            nv.a = words; nv.b = words + n; nv.escape = words + 2 * (size_t)n;
+            __syncthreads();
+        }
     }
+    if constexpr (T::WORLD == 2) queue = reinterpret_cast<uint16_t *>(lds_raw) + (threadIdx.x >> 6) * (kQueueCap * 64);
 
-    const Vec background = load3(sc.camera.bg);
+    // ---- persistent waves: every lane pulls pixels from one atomic cursor until the frame is done ----
+    // Slots are numbered tile-major (8x8 tiles, row-major inside a tile) so that lanes refilled together
+    // start on neighbouring pixels; a slot outside the frame is simply skipped.
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tiles_x = ((uint32_t)a.width + 7u) >> 3;
+    const uint32_t total_slots = tiles_x * (((uint32_t)a.rows_owned + 7u) >> 3) * 64u;
+    const CameraRec *__restrict__ cam = sc.camera;
+
+    bool active = false, exhausted = false;
+    int i = 0, j = 0;
+    size_t local = 0;
+    Xorwow rng{0, 0, 0, 0, 0, 0};
     Vec col = mk(0.0, 0.0, 0.0);
     Vec throughput = mk(1.0, 1.0, 1.0), accumulated = mk(0.0, 0.0, 0.0);
     Ray ray{};
     int sample = 0, depth = 0;
-    unsigned long long nrays = 0;
-    if (active) ray = camera_ray(sc.camera, i, j, a.width, a.height, rng);
+    uint32_t nrays = 0;
 
-    // Flat loop: every iteration traces one ray segment for every lane that still has samples left.
-    while (active) {
+    for (;;) {
+        if (!exhausted) {
+            const unsigned long long need = __ballot(!active);
+            if (need) {
+                const uint32_t cnt = (uint32_t)__popcll(need);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.cursor, cnt);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + cnt >= total_slots) exhausted = true;
+                const uint32_t slot = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (!active && slot < total_slots) {
+                    const uint32_t tile = slot >> 6, w = slot & 63u;
+                    const int pi = (int)((tile % tiles_x) * 8u + (w & 7u));
+                    const int lr = (int)((tile / tiles_x) * 8u + (w >> 3));
+                    if (pi < a.width && lr < a.rows_owned) {
+                        i = pi;
+                        j = owned_row(lr, a.stripe_rows, a.rank, a.world_size);
+                        local = (size_t)lr * (size_t)a.width + (size_t)pi;
+                        rng.d = a.state[0 * (size_t)a.n_pixels + local];
+                        rng.v0 = a.state[1 * (size_t)a.n_pixels + local];
+                        rng.v1 = a.state[2 * (size_t)a.n_pixels + local];
+                        rng.v2 = a.state[3 * (size_t)a.n_pixels + local];
+                        rng.v3 = a.state[4 * (size_t)a.n_pixels + local];
+                        rng.v4 = a.state[5 * (size_t)a.n_pixels + local];
+                        col = mk(0.0, 0.0, 0.0);
+                        throughput = mk(1.0, 1.0, 1.0);
+                        accumulated = mk(0.0, 0.0, 0.0);
+                        sample = 0;
+                        depth = 0;
+                        ray = camera_ray(cam, i, j, a.width, a.height, rng);
+                        active = true;
+                    }
+                }
+            }
+        }
+        const unsigned long long live = __ballot(active);
+        if (!live) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- one ray segment for every live lane ----
         HitInfo h;
         h.t = 0.0;
         h.ref = kNone;
         h.obj = kNone;
-        nrays++;
-        bool hit = (sc.world_kind == WORLD_BVH) ? world_hit_bvh(sc, ray, 0.001, DBL_MAX, h, rng)
-                                                 : world_hit_list(sc, ray, 0.001, DBL_MAX, h, rng);
-        bool path_ends;
-        if (!hit) {  // R/kernel.cu:74-79
-            accumulated = accumulated + throughput * background;
-            path_ends = true;
-        } else {
-            Surface s = make_surface(sc, ray, h);
-            path_ends = !shade(sc, s, ray, throughput, accumulated, rng);
-            if (!path_ends && ++depth >= a.max_depth) path_ends = true;  // R/kernel.cu:71,97
-        }
-        if (path_ends) {  // R/kernel.cu:143: col += RayColor(...)
-            col = col + accumulated;
-            if (++sample < a.spp) {
-                ray = camera_ray(sc.camera, i, j, a.width, a.height, rng);
-                throughput = mk(1.0, 1.0, 1.0);
-                accumulated = mk(0.0, 0.0, 0.0);
-                depth = 0;
+        bool hit = false;
+        if constexpr (T::WORLD == 2) {
+            if (__popcll(live) >= a.coop_threshold) {
+                if (active) hit = scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h);
             } else {
-                active = false;
+                scan_cooperative(sc, lane, live, ray, 0.001, DBL_MAX, h, hit);
+            }
+        }
+        if (active) {
+            nrays++;
+            if constexpr (T::WORLD == 0) hit = world_hit_bvh<T>(sc, nv, ray, 0.001, DBL_MAX, h, rng);
+            else if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng);
+            bool path_ends;
+            if (!hit) {  // R/kernel.cu:74-79
+                accumulated = accumulated + throughput * load3(cam->bg);
+                path_ends = true;
+            } else {
+                Surface s = make_surface<T>(sc, ray, h);
+                path_ends = !shade<T>(sc, s, ray, throughput, accumulated, rng);
+                if (!path_ends && ++depth >= a.max_depth) path_ends = true;  // R/kernel.cu:71,97
+            }
+            if (path_ends) {  // R/kernel.cu:143: col += RayColor(...)
+                col = col + accumulated;
+                if (++sample < a.spp) {
+                    ray = camera_ray(cam, i, j, a.width, a.height, rng);
+                    throughput = mk(1.0, 1.0, 1.0);
+                    accumulated = mk(0.0, 0.0, 0.0);
+                    depth = 0;
+                } else {
+                    // R/kernel.cu:146-153: save the RNG state, average, gamma 2
+                    a.state[0 * (size_t)a.n_pixels + local] = rng.d;
+                    a.state[1 * (size_t)a.n_pixels + local] = rng.v0;
+                    a.state[2 * (size_t)a.n_pixels + local] = rng.v1;
+                    a.state[3 * (size_t)a.n_pixels + local] = rng.v2;
+                    a.state[4 * (size_t)a.n_pixels + local] = rng.v3;
+                    a.state[5 * (size_t)a.n_pixels + local] = rng.v4;
+                    col = over(col, (double)a.spp);
+                    a.pixels[local * 3 + 0] = sqrt(col.x);
+                    a.pixels[local * 3 + 1] = sqrt(col.y);
+                    a.pixels[local * 3 + 2] = sqrt(col.z);
+                    active = false;
+                }
             }
         }
     }
 
-    if (i < a.width && lr < a.rows_owned) {
-        // R/kernel.cu:146-153: save the RNG state, average, gamma 2
-        a.state[0 * (size_t)a.n_pixels + local] = rng.d;
-        a.state[1 * (size_t)a.n_pixels + local] = rng.v0;
-        a.state[2 * (size_t)a.n_pixels + local] = rng.v1;
-        a.state[3 * (size_t)a.n_pixels + local] = rng.v2;
-        a.state[4 * (size_t)a.n_pixels + local] = rng.v3;
-        a.state[5 * (size_t)a.n_pixels + local] = rng.v4;
-        if (a.spp > 0) {
-            col = over(col, (double)a.spp);
-            a.pixels[local * 3 + 0] = sqrt(col.x);
-            a.pixels[local * 3 + 1] = sqrt(col.y);
-            a.pixels[local * 3 + 2] = sqrt(col.z);
-        }
-    }
     // one atomic per wave for the ray counter
-    for (int off = 32; off > 0; off >>= 1) nrays += __shfl_down(nrays, off, 64);
-    if (lane == 0 && nrays) atomicAdd(a.ray_counter, nrays);
+    unsigned long long total = nrays;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    if (lane == 0 && total) atomicAdd(a.ray_counter, total);
 }
 
 #if RT_STRICT
@@ -722,23 +987,73 @@ hipError_t RT_CAT(launch_seed_, RT_SUFFIX)(const SeedArgs &a, hipStream_t stream
     return hipGetLastError();
 }
 
-hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream)
+namespace {
+using TSphereList = Traits<2, false, false>;
+using TBvhPrims = Traits<0, false, false>;
+using TBvhGeneral = Traits<0, true, true>;
+using TListGeneral = Traits<1, true, true>;
+
+template <class T>
+hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, KernelInfo *info)
 {
-    if (a.n_pixels == 0) return hipSuccess;
+    auto kernel = render_kernel<RT_STRICT, T>;
     uint32_t tiles = (((uint32_t)a.width + 7u) >> 3) * (((uint32_t)a.rows_owned + 7u) >> 3);
-    dim3 grid((tiles + 3u) / 4u), block(256);
-    hipLaunchKernelGGL(render_kernel<RT_STRICT>, grid, block, 0, stream, sc, a);
+    size_t lds = 0;
+    a.lds_nodes = 0;
+    if (T::WORLD == 0) {
+        size_t need = (size_t)sc.n_nodes * (6 * sizeof(double) + 3 * sizeof(uint32_t));
+        if (need <= 60 * 1024) {  // keep >= 2 workgroups per CU resident
+            lds = need;
+            a.lds_nodes = 1;
+        }
+    } else if (T::WORLD == 2) {
+        lds = 4 * kQueueCap * 64 * sizeof(uint16_t);
+    }
+    if (info) {
+        hipFuncAttributes attr;
+        hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel));
+        if (e != hipSuccess) return e;
+        info->vgprs = attr.numRegs;
+        info->lds_bytes = (int)(attr.sharedSizeBytes + lds);
+        info->kind = T::WORLD * 4 + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0);
+        return hipSuccess;
+    }
+    if (a.n_pixels == 0 || a.spp <= 0) return hipSuccess;
+    // persistent grid: as many workgroups as the chip holds at once (never more than there are tiles)
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    uint32_t resident = (uint32_t)per_cu * (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
+    uint32_t blocks = (tiles + 3u) / 4u;
+    if (blocks > resident) blocks = resident;
+    dim3 grid(blocks), block(256);
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, a);
     return hipGetLastError();
 }
 
-hipError_t RT_CAT(kernel_attributes_, RT_SUFFIX)(int *vgprs, int *lds_bytes)
+hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info)
 {
-    hipFuncAttributes attr;
-    hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&render_kernel<RT_STRICT>));
-    if (e != hipSuccess) return e;
-    *vgprs = attr.numRegs;
-    *lds_bytes = (int)attr.sharedSizeBytes;
-    return hipSuccess;
+    const bool composite = sc.n_objects != 0;
+    const bool rich = (sc.flags & SCENE_RICH_TEXTURES) != 0;
+    if ((sc.flags & SCENE_LIST_ALL_SPHERES) && !rich && sc.n_spheres <= 65535u && !a.force_general)
+        return launch_one<TSphereList>(sc, a, stream, info);
+    if (sc.world_kind == WORLD_BVH) {
+        if (!composite && !rich && !a.force_general) return launch_one<TBvhPrims>(sc, a, stream, info);
+        return launch_one<TBvhGeneral>(sc, a, stream, info);
+    }
+    return launch_one<TListGeneral>(sc, a, stream, info);
+}
+} // namespace
+
+hipError_t RT_CAT(launch_render_, RT_SUFFIX)(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream)
+{
+    return dispatch(sc, a, stream, nullptr);
+}
+
+hipError_t RT_CAT(kernel_info_, RT_SUFFIX)(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info)
+{
+    return dispatch(sc, a, nullptr, info);
 }
 
 } // namespace rtow

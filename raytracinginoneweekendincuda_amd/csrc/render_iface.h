@@ -21,17 +21,26 @@ struct RenderArgs {
     double *pixels;              // rows_owned x width x 3
     uint32_t *state;
     unsigned long long *ray_counter;
+    uint32_t *cursor;            // pixel-queue cursor, zeroed before every launch
     uint32_t n_pixels;
     int32_t width, height, rows_owned;
     int32_t spp, max_depth;
     int32_t stripe_rows, rank, world_size;
+    int32_t lds_nodes;      // set by the launcher: BVH nodes are staged in LDS
+    int32_t force_general;  // tests: use the general kernel even where a specialised one applies
+    int32_t coop_threshold; // sphere-list kernel: below this many live lanes a wave scans cooperatively
+    int32_t num_cus;
+};
+
+struct KernelInfo {
+    int vgprs, lds_bytes, kind;  // kind = WORLD * 4 + COMPOSITE * 2 + RICH
 };
 
 hipError_t launch_seed_strict(const SeedArgs &a, hipStream_t stream);
 hipError_t launch_seed_fast(const SeedArgs &a, hipStream_t stream);
 hipError_t launch_render_strict(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream);
 hipError_t launch_render_fast(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream);
-hipError_t kernel_attributes_strict(int *vgprs, int *lds_bytes);
-hipError_t kernel_attributes_fast(int *vgprs, int *lds_bytes);
+hipError_t kernel_info_strict(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info);
+hipError_t kernel_info_fast(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info);
 
 } // namespace rtow

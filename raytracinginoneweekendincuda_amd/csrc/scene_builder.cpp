@@ -401,6 +401,7 @@ static void lower_materials(SceneImpl &s, FlatScene &f)
         r.kind = t.kind;
         r.r = t.color.x; r.g = t.color.y; r.b = t.color.z;
         r.s = t.s;
+        if (t.kind == TEX_IMAGE || t.kind == TEX_NOISE) f.flags |= SCENE_RICH_TEXTURES;
         if (t.kind == TEX_CHECKER) {
             r.a = t.a - 1;
             r.b_ = t.b - 1;

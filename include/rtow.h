@@ -144,10 +144,11 @@ typedef struct rt_render_params {
     int32_t flags;                /* RT_FLAG_* */
     void *stream;                 /* hipStream_t to launch on (NULL = the film's own stream) */
     int32_t coop_threshold;       /* tuning: sphere-list waves with fewer live lanes scan cooperatively (0 = default) */
-    int32_t reserved;
+    int32_t overdue_rays_per_sample; /* tuning: a pixel past this many rays/sample is finished cooperatively (0 = default 8, <0 = never) */
 } rt_render_params;
 
 #define RT_FLAG_KEEP_RNG_STATE 1u  /* do not re-seed: continue from the film's saved per-pixel state (progressive) */
+#define RT_FLAG_OVERDUE_PRIORITY 4u /* tuning/diagnostics: overdue pixels raise their wave's priority instead of going cooperative */
 #define RT_FLAG_FORCE_GENERAL 2u   /* tests: run the general kernel even where a specialised instantiation applies */
 
 typedef struct rt_render_stats {

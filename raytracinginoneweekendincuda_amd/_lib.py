@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtow_hip.so")
+LIB_PATH = os.environ.get("RTOW_LIB_PATH") or os.path.join(_HERE, "librtow_hip.so")  # override: A/B builds only
 
 
 class RenderParams(C.Structure):
@@ -11,7 +11,7 @@ class RenderParams(C.Structure):
         ("width", C.c_int32), ("height", C.c_int32), ("samples_per_pixel", C.c_int32), ("max_depth", C.c_int32),
         ("seed", C.c_uint64), ("stripe_rows", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
         ("variant", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
-        ("coop_threshold", C.c_int32), ("reserved", C.c_int32),
+        ("coop_threshold", C.c_int32), ("overdue_rays_per_sample", C.c_int32),
     ]
 
 

@@ -271,6 +271,14 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 1);
     ra.coop_threshold = p->coop_threshold > 0 ? p->coop_threshold : 24;
     ra.num_cus = f.num_cus;
+    ra.overdue_priority = (p->flags & RT_FLAG_OVERDUE_PRIORITY) ? 1 : 0;
+    {
+        // default budget: 8 rays per sample (about the 98th percentile of the Book-1 scenes)
+        double per_sample = p->overdue_rays_per_sample > 0 ? (double)p->overdue_rays_per_sample : 8.0;
+        double budget = per_sample * (double)p->samples_per_pixel;
+        ra.ray_budget = budget >= 4.0e9 ? 0xFFFFFFFFu : (uint32_t)budget;
+        if (p->overdue_rays_per_sample < 0) ra.ray_budget = 0xFFFFFFFFu;  // negative: never
+    }
     ra.n_pixels = f.n_pixels;
     ra.width = f.width;
     ra.height = f.height;

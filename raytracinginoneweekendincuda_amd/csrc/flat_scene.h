@@ -56,8 +56,16 @@ struct BvhNodeRec { double xlo, xhi, ylo, yhi, zlo, zhi; uint32_t a, b, escape, 
 
 // Materials (R/Material.h, R/Metal.h, R/Dielectric.h)
 enum : uint32_t { MAT_LAMBERTIAN = 0u, MAT_METAL = 1u, MAT_DIELECTRIC = 2u, MAT_DIFFUSE_LIGHT = 3u, MAT_ISOTROPIC = 4u };
-struct MaterialRec { double r, g, b, p; uint32_t kind, tex, needs_uv, pad1; };  // metal: rgb + fuzz; dielectric: p = ior
-// needs_uv: the texture tree contains an ImageTexture, the only reader of HitRecord::U/V (R/Texture.h:110-133)
+// metal: rgb + fuzz; dielectric: p = ior.
+// needs_uv: the texture tree contains an ImageTexture, the only reader of HitRecord::U/V (R/Texture.h:110-133).
+// tex_inline: the texture is a SolidColor (1) or a CheckerTexture of two SolidColors (2), resolved by the host
+// into even/odd/inv_scale so that shading needs no dependent texture-table loads; 0 = walk the texture table.
+struct MaterialRec {
+    double r, g, b, p;
+    uint32_t kind, tex, needs_uv, tex_inline;
+    double even[3], odd[3], inv_scale;
+    double pad;
+};
 
 // Textures (R/Texture.h)
 enum : uint32_t { TEX_SOLID = 0u, TEX_CHECKER = 1u, TEX_IMAGE = 2u, TEX_NOISE = 3u };

@@ -36,8 +36,9 @@ namespace {
 //              2 = HittableList of static spheres only (config C2: scalar-fed discriminant scan + LDS queue)
 //   COMPOSITE  instances / boxes / lists / media may appear as leaves
 //   RICH       Perlin-noise or image textures may appear
-template <int WORLD_, bool COMPOSITE_, bool RICH_>
+template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1>
 struct Traits {
+    static constexpr int MIN_WAVES = MIN_WAVES_;  // waves per SIMD the register allocator must leave room for
     static constexpr int WORLD = WORLD_;
     static constexpr bool COMPOSITE = COMPOSITE_;
     static constexpr bool RICH = RICH_;
@@ -71,6 +72,21 @@ struct NodeView {
 };
 
 #define DEV __device__ __forceinline__
+
+// Scene tables are immutable for the whole launch.  Reading them through the constant address space tells
+// the compiler so: a wave-uniform row then always comes through the scalar cache into SGPRs, even though the
+// kernel stores pixels inside its main loop (which defeats alias analysis for ordinary global loads).
+#define RT_CONST __attribute__((address_space(4)))
+template <class T>
+DEV const RT_CONST double *const_doubles(const T *p)
+{
+    return (const RT_CONST double *)(uintptr_t)p;
+}
+DEV SphereGeom load_sphere_row(const SphereGeom *table, uint32_t k)
+{
+    const RT_CONST double *p = const_doubles(table + k);
+    return SphereGeom{p[0], p[1], p[2], p[3]};
+}
 
 DEV Vec mk(double x, double y, double z) { return Vec{x, y, z}; }
 DEV Vec operator+(Vec a, Vec b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -474,16 +490,18 @@ DEV bool scan_uniform(const DeviceScene &sc, uint16_t *queue, uint32_t lane, con
     // groups of four rows, the next group's scalar loads in flight while this group is evaluated
     SphereGeom g0{}, g1{}, g2{}, g3{};
     if (n4) {
-        g0 = spheres[0]; g1 = spheres[1]; g2 = spheres[2]; g3 = spheres[3];
+        g0 = load_sphere_row(spheres, 0); g1 = load_sphere_row(spheres, 1);
+        g2 = load_sphere_row(spheres, 2); g3 = load_sphere_row(spheres, 3);
     }
     for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
         const uint32_t kn = (k0 + 4 < n4) ? k0 + 4 : k0;  // last group re-reads itself (stays in bounds)
-        const SphereGeom h0 = spheres[kn], h1 = spheres[kn + 1], h2 = spheres[kn + 2], h3 = spheres[kn + 3];
+        const SphereGeom h0 = load_sphere_row(spheres, kn), h1 = load_sphere_row(spheres, kn + 1);
+        const SphereGeom h2 = load_sphere_row(spheres, kn + 2), h3 = load_sphere_row(spheres, kn + 3);
         scan_four(g0, g1, g2, g3, k0, r, a, queue, lane, count);
         g0 = h0; g1 = h1; g2 = h2; g3 = h3;
         if (__any(count > (uint32_t)(kQueueCap - kScanUnroll))) drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
     }
-    for (uint32_t k = n4; k < n; k++) scan_one(spheres[k], k, r, a, queue, lane, count);
+    for (uint32_t k = n4; k < n; k++) scan_one(load_sphere_row(spheres, k), k, r, a, queue, lane, count);
     drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
     if (best_k == kNone) return false;
     best.t = closest;
@@ -499,15 +517,47 @@ DEV double bcast(double x, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
-// Ray-cooperative scan for sparse waves: all 64 lanes work on ONE ray (lane `src`'s), lane l testing spheres
-// l, l+64, ...; then a wave-wide min over (t, index).  Same winner as the sequential scan: that scan returns
-// the smallest "first acceptable root" over all spheres with ties going to the lowest index, and a root that
-// would have been rejected only because of an earlier closer hit loses the min here as well.
-DEV void scan_cooperative(const DeviceScene &sc, uint32_t lane, unsigned long long todo, const Ray &ray, double tmin, double tmax,
+// Sphere table as seen by the cooperative scan: four SoA planes in LDS (consecutive lanes read consecutive
+// 8-byte words: conflict-free), or the global AoS table when it does not fit.
+struct SphereView {
+    const double *cx, *cy, *cz, *r2;  // LDS planes, padded to a multiple of 64 with unhittable spheres
+    const SphereGeom *global;
+    uint32_t n, n_padded;
+    bool in_lds;
+};
+
+// Wave-wide minimum of (t, k) pairs with DPP row operations (no LDS traffic); result valid in every lane.
+// t > 0 always, so comparing (t, k) lexicographically picks the closest root, lowest sphere index on ties.
+template <int CTRL, int ROW_MASK>
+DEV void min_step(double &t, uint32_t &k)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(t), __double2loint(t), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(t), __double2hiint(t), CTRL, ROW_MASK, 0xf, false);
+    uint32_t ok = (uint32_t)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, ROW_MASK, 0xf, false);
+    double ot = __hiloint2double(hi, lo);
+    bool take = (ot < t) || (ot == t && ok < k);
+    t = take ? ot : t;
+    k = take ? ok : k;
+}
+DEV void wave_min(double &t, uint32_t &k)
+{
+    min_step<0xB1, 0xf>(t, k);   // quad_perm [1,0,3,2]
+    min_step<0x4E, 0xf>(t, k);   // quad_perm [2,3,0,1]
+    min_step<0x114, 0xf>(t, k);  // row_shr:4
+    min_step<0x118, 0xf>(t, k);  // row_shr:8   -> lane 15 of each row holds the row minimum
+    min_step<0x142, 0xa>(t, k);  // row_bcast:15 into rows 1 and 3
+    min_step<0x143, 0xc>(t, k);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+    t = bcast(t, 63);
+    k = (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+}
+
+// Ray-cooperative scan: all 64 lanes work on ONE ray (lane `src`'s), lane l testing spheres l, l+64, ...;
+// then a wave-wide min over (t, index).  Same winner as the sequential scan: that scan returns the smallest
+// "first acceptable root" over all spheres with ties going to the lowest index, and a root that would have
+// been rejected only because of an earlier closer hit loses the min here as well.
+DEV void scan_cooperative(const SphereView &sv, uint32_t lane, unsigned long long todo, const Ray &ray, double tmin, double tmax,
                           HitInfo &best, bool &hit)
 {
-    const SphereGeom *__restrict__ spheres = sc.spheres;
-    const uint32_t n = sc.n_spheres;
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -517,29 +567,48 @@ DEV void scan_cooperative(const DeviceScene &sc, uint32_t lane, unsigned long lo
         const double a = dot(r.d, r.d);
         double bt = tmax;
         uint32_t bk = kNone;
-        for (uint32_t k = lane; k < n; k += 64u) {
-            SphereGeom g = spheres[k];
-            Vec oc = r.o - mk(g.cx, g.cy, g.cz);
-            double b = dot(oc, r.d);
-            double c = dot(oc, oc) - g.r2;
-            double disc = b * b - a * c;
-            if (disc > 0.0 && !(b > 0.0 && c > 0.0)) {
-                double t;
-                if (sphere_roots(b, disc, a, tmin, bt, t)) {
-                    bt = t;
-                    bk = k;
+        if (sv.in_lds) {
+            for (uint32_t base = 0; base < sv.n_padded; base += 256u) {
+                double b[4], c[4], disc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    // rows past n_padded are never read: clamp keeps the address inside the planes
+                    uint32_t k = base + 64u * u + lane;
+                    k = k < sv.n_padded ? k : sv.n_padded - 1u;
+                    Vec oc = r.o - mk(sv.cx[k], sv.cy[k], sv.cz[k]);
+                    b[u] = dot(oc, r.d);
+                    c[u] = dot(oc, oc) - sv.r2[k];
+                    disc[u] = b[u] * b[u] - a * c[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = base + 64u * u + lane;
+                    if (k < sv.n && disc[u] > 0.0 && !(b[u] > 0.0 && c[u] > 0.0)) {
+                        double t;
+                        if (sphere_roots(b[u], disc[u], a, tmin, bt, t)) {
+                            bt = t;
+                            bk = k;
+                        }
+                    }
+                }
+            }
+        } else {
+            for (uint32_t k = lane; k < sv.n; k += 64u) {
+                SphereGeom g = sv.global[k];
+                Vec oc = r.o - mk(g.cx, g.cy, g.cz);
+                double b = dot(oc, r.d);
+                double c = dot(oc, oc) - g.r2;
+                double disc = b * b - a * c;
+                if (disc > 0.0 && !(b > 0.0 && c > 0.0)) {
+                    double t;
+                    if (sphere_roots(b, disc, a, tmin, bt, t)) {
+                        bt = t;
+                        bk = k;
+                    }
                 }
             }
         }
-        // wave min over (t, k); lanes without a hit carry (tmax, kNone) and lose every comparison
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            double ot = __shfl_xor(bt, off, 64);
-            uint32_t ok = (uint32_t)__shfl_xor((int)bk, off, 64);
-            bool take = (ot < bt) || (ot == bt && ok < bk);
-            bt = take ? ot : bt;
-            bk = take ? ok : bk;
-        }
+        wave_min(bt, bk);
         if ((int)lane == src) {
             hit = bk != kNone;
             best.t = bt;
@@ -705,6 +774,20 @@ DEV Vec texture_value(const DeviceScene &sc, uint32_t ti, double u, double v, Ve
     return mk(t.r, t.g, t.b);  // TEX_SOLID, R/Texture.h:48-51
 }
 
+// Texture of a material: host-resolved solid / checker-of-solids without touching the texture table.
+template <class T>
+DEV Vec material_texture(const DeviceScene &sc, const MaterialRec &m, double u, double v, Vec p)
+{
+    if (m.tex_inline == 1) return mk(m.even[0], m.even[1], m.even[2]);
+    if (m.tex_inline == 2) {  // R/Texture.h:70-81
+        int xi = (int)floor(m.inv_scale * p.x), yi = (int)floor(m.inv_scale * p.y), zi = (int)floor(m.inv_scale * p.z);
+        bool even = ((xi + yi + zi) % 2) == 0;
+        return even ? mk(m.even[0], m.even[1], m.even[2]) : mk(m.odd[0], m.odd[1], m.odd[2]);
+    }
+    if constexpr (T::RICH) return texture_value<T>(sc, m.tex, u, v, p);
+    return mk(0.0, 0.0, 0.0);  // unreachable: scenes with table-walking textures run the RICH instantiation
+}
+
 DEV Vec random_in_unit_sphere(Xorwow &rng)  // R/Material.h:14-24
 {
     Vec p;
@@ -718,28 +801,34 @@ DEV Vec random_in_unit_sphere(Xorwow &rng)  // R/Material.h:14-24
 }
 
 // Emitted + Scatter (R/kernel.cu:82-94).  Returns false when the path ends here.
+// The in-sphere sample (Lambertian, Metal, Isotropic) and the unit direction (Metal, Dielectric) are evaluated
+// once, ahead of the material switch, for the lanes whose material uses them: in each of those Scatter
+// functions the sample is the first thing drawn from the RNG, so the per-pixel draw order is unchanged.
 template <class T>
 DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughput, Vec &accumulated, Xorwow &rng)
 {
-    MaterialRec m = sc.materials[s.mat];
+    const MaterialRec m = sc.materials[s.mat];
     Vec atten;
     Ray out;
     out.o = s.p;
     out.tm = ray.tm;
+    Vec rs = mk(0.0, 0.0, 0.0), ud = mk(0.0, 0.0, 0.0);
+    if (m.kind == MAT_LAMBERTIAN || m.kind == MAT_METAL || m.kind == MAT_ISOTROPIC) rs = random_in_unit_sphere(rng);
+    if (m.kind == MAT_METAL || m.kind == MAT_DIELECTRIC) ud = unit(ray.d);
     switch (m.kind) {
     case MAT_DIFFUSE_LIGHT:  // R/Material.h:114-127: emits on both sides, never scatters
-        accumulated = accumulated + throughput * texture_value<T>(sc, m.tex, s.u, s.v, s.p);
+        accumulated = accumulated + throughput * material_texture<T>(sc, m, s.u, s.v, s.p);
         return false;
     case MAT_LAMBERTIAN: {  // R/Material.h:67-82
-        Vec dir = s.n + random_in_unit_sphere(rng);
+        Vec dir = s.n + rs;
         if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = s.n;
         out.d = dir;
-        atten = texture_value<T>(sc, m.tex, s.u, s.v, s.p);
+        atten = material_texture<T>(sc, m, s.u, s.v, s.p);
         break;
     }
     case MAT_METAL: {  // R/Metal.h:18-30
-        Vec refl = reflect(unit(ray.d), s.n);
-        out.d = refl + m.p * random_in_unit_sphere(rng);
+        Vec refl = reflect(ud, s.n);
+        out.d = refl + m.p * rs;
         atten = mk(m.r, m.g, m.b);
         if (!(dot(out.d, s.n) > 0.0)) return false;
         break;
@@ -747,7 +836,6 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
     case MAT_DIELECTRIC: {  // R/Dielectric.h:18-68
         atten = mk(1.0, 1.0, 1.0);
         double ratio = s.front ? (1.0 / m.p) : m.p;
-        Vec ud = unit(ray.d);
         double ct = fmin(dot(-ud, s.n), 1.0);
         double st = sqrt(1.0 - ct * ct);
         bool reflect_it = ratio * st > 1.0;
@@ -761,8 +849,8 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
         break;
     }
     default: {  // MAT_ISOTROPIC, R/Material.h:152-163
-        out.d = unit(random_in_unit_sphere(rng));
-        atten = texture_value<T>(sc, m.tex, s.u, s.v, s.p);
+        out.d = unit(rs);
+        atten = material_texture<T>(sc, m, s.u, s.v, s.p);
         break;
     }
     }
@@ -772,8 +860,11 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
 }
 
 // Camera::GetRay (R/Camera.h:76-85) behind the pixel jitter of Render (R/kernel.cu:140-142).
-DEV Ray camera_ray(const CameraRec *__restrict__ cam, int i, int j, int width, int height, Xorwow &rng)
+DEV Vec load3c(const RT_CONST double *p) { return mk(p[0], p[1], p[2]); }
+
+DEV Ray camera_ray(const CameraRec *cam_generic, int i, int j, int width, int height, Xorwow &rng)
 {
+    const RT_CONST CameraRec *cam = (const RT_CONST CameraRec *)(uintptr_t)cam_generic;
     double u = (double)((float)i + xorwow_uniform(rng)) / (double)width;   // int + float adds in fp32
     double v = (double)((float)j + xorwow_uniform(rng)) / (double)height;
     Vec p;
@@ -783,13 +874,13 @@ DEV Ray camera_ray(const CameraRec *__restrict__ cam, int i, int j, int width, i
         p = 2.0 * mk(a, b, 0.0) - mk(1.0, 1.0, 0.0);
     } while (dot(p, p) >= 1.0);
     Vec rd = cam->lens_radius * p;
-    Vec cu = load3(cam->u), cv = load3(cam->v);
+    Vec cu = load3c(cam->u), cv = load3c(cam->v);
     Vec offset = rd.x * cu + rd.y * cv;
     double tm = cam->time0 + (double)xorwow_uniform(rng) * (cam->time1 - cam->time0);
-    Vec origin = load3(cam->origin);
+    Vec origin = load3c(cam->origin);
     Ray r;
     r.o = origin + offset;
-    r.d = load3(cam->llc) + u * load3(cam->horizontal) + v * load3(cam->vertical) - origin - offset;
+    r.d = load3c(cam->llc) + u * load3c(cam->horizontal) + v * load3c(cam->vertical) - origin - offset;
     r.tm = tm;
     return r;
 }
@@ -826,7 +917,7 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a)
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 template <int STRICT, class T>
-__global__ __launch_bounds__(256) void render_kernel(DeviceScene sc, RenderArgs a)
+__global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene sc, RenderArgs a)
 {
     // ---- chip-resident working set ----
     NodeView nv{};
@@ -853,7 +944,24 @@ __global__ __launch_bounds__(256) void render_kernel(DeviceScene sc, RenderArgs 
             __syncthreads();
         }
     }
-    if constexpr (T::WORLD == 2) queue = reinterpret_cast<uint16_t *>(lds_raw) + (threadIdx.x >> 6) * (kQueueCap * 64);
+    SphereView sv{};
+    if constexpr (T::WORLD == 2) {
+        queue = reinterpret_cast<uint16_t *>(lds_raw) + (threadIdx.x >> 6) * (kQueueCap * 64);
+        sv.global = sc.spheres;
+        sv.n = sc.n_spheres;
+        sv.n_padded = (sc.n_spheres + 63u) & ~63u;
+        sv.in_lds = a.lds_spheres != 0;
+        if (sv.in_lds) {
+            double *planes = reinterpret_cast<double *>(lds_raw + 4 * kQueueCap * 64 * sizeof(uint16_t));
+            const uint32_t np = sv.n_padded;
+            for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+                SphereGeom g = sc.spheres[k < sv.n ? k : 0];
+                planes[k] = g.cx; planes[np + k] = g.cy; planes[2 * np + k] = g.cz; planes[3 * np + k] = g.r2;
+            }
+            sv.cx = planes; sv.cy = planes + np; sv.cz = planes + 2 * (size_t)np; sv.r2 = planes + 3 * (size_t)np;
+            __syncthreads();
+        }
+    }
 
     // ---- persistent waves: every lane pulls pixels from one atomic cursor until the frame is done ----
     // Slots are numbered tile-major (8x8 tiles, row-major inside a tile) so that lanes refilled together
@@ -873,8 +981,23 @@ __global__ __launch_bounds__(256) void render_kernel(DeviceScene sc, RenderArgs 
     int sample = 0, depth = 0;
     uint32_t nrays = 0;
 
+    uint32_t pix_rays = 0;  // rays this lane's current pixel has traced so far
+
     for (;;) {
-        if (!exhausted) {
+        // A pixel that has used up its ray budget is "overdue": its samples cannot be spread over lanes (one
+        // sequential RNG stream per pixel), so instead the whole wave works on each of its rays (cooperative
+        // scan) until it is finished -- that bounds the frame's critical path by the budget, not by the pixel.
+        unsigned long long overdue = 0;
+        if constexpr (T::WORLD == 2) {
+            overdue = __ballot(active && pix_rays >= a.ray_budget);
+            if (a.overdue_priority) {  // diagnostic alternative: keep the pixel-parallel scan but raise this wave's issue priority
+                if (overdue) __builtin_amdgcn_s_setprio(3);
+                else __builtin_amdgcn_s_setprio(0);
+                overdue = 0;
+            }
+        }
+
+        if (!exhausted && !overdue) {
             const unsigned long long need = __ballot(!active);
             if (need) {
                 const uint32_t cnt = (uint32_t)__popcll(need);
@@ -902,6 +1025,7 @@ __global__ __launch_bounds__(256) void render_kernel(DeviceScene sc, RenderArgs 
                         accumulated = mk(0.0, 0.0, 0.0);
                         sample = 0;
                         depth = 0;
+                        pix_rays = 0;
                         ray = camera_ray(cam, i, j, a.width, a.height, rng);
                         active = true;
                     }
@@ -914,26 +1038,29 @@ __global__ __launch_bounds__(256) void render_kernel(DeviceScene sc, RenderArgs 
             continue;
         }
 
-        // ---- one ray segment for every live lane ----
+        // ---- one ray segment for every lane in `todo` ----
+        unsigned long long todo = live;
         HitInfo h;
         h.t = 0.0;
         h.ref = kNone;
         h.obj = kNone;
         bool hit = false;
         if constexpr (T::WORLD == 2) {
-            if (__popcll(live) >= a.coop_threshold) {
+            if (overdue) todo = overdue & (~overdue + 1ull);  // one overdue pixel at a time, lowest lane first
+            if (!overdue && __popcll(live) >= a.coop_threshold) {
                 if (active) hit = scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h);
             } else {
-                scan_cooperative(sc, lane, live, ray, 0.001, DBL_MAX, h, hit);
+                scan_cooperative(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
             }
         }
-        if (active) {
+        if ((todo >> lane) & 1ull) {
             nrays++;
+            pix_rays++;
             if constexpr (T::WORLD == 0) hit = world_hit_bvh<T>(sc, nv, ray, 0.001, DBL_MAX, h, rng);
             else if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng);
             bool path_ends;
             if (!hit) {  // R/kernel.cu:74-79
-                accumulated = accumulated + throughput * load3(cam->bg);
+                accumulated = accumulated + throughput * load3c(((const RT_CONST CameraRec *)(uintptr_t)cam)->bg);
                 path_ends = true;
             } else {
                 Surface s = make_surface<T>(sc, ray, h);
@@ -988,8 +1115,14 @@ hipError_t RT_CAT(launch_seed_, RT_SUFFIX)(const SeedArgs &a, hipStream_t stream
 }
 
 namespace {
-using TSphereList = Traits<2, false, false>;
-using TBvhPrims = Traits<0, false, false>;
+#ifndef RT_WAVES_SPHERES
+#define RT_WAVES_SPHERES 3
+#endif
+#ifndef RT_WAVES_BVH
+#define RT_WAVES_BVH 3
+#endif
+using TSphereList = Traits<2, false, false, RT_WAVES_SPHERES>;
+using TBvhPrims = Traits<0, false, false, RT_WAVES_BVH>;
 using TBvhGeneral = Traits<0, true, true>;
 using TListGeneral = Traits<1, true, true>;
 
@@ -1008,6 +1141,12 @@ hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, K
         }
     } else if (T::WORLD == 2) {
         lds = 4 * kQueueCap * 64 * sizeof(uint16_t);
+        size_t planes = (size_t)((sc.n_spheres + 63u) & ~63u) * 4 * sizeof(double);
+        a.lds_spheres = 0;
+        if (planes <= 48 * 1024) {
+            lds += planes;
+            a.lds_spheres = 1;
+        }
     }
     if (info) {
         hipFuncAttributes attr;

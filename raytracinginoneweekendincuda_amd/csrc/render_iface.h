@@ -30,6 +30,9 @@ struct RenderArgs {
     int32_t force_general;  // tests: use the general kernel even where a specialised one applies
     int32_t coop_threshold; // sphere-list kernel: below this many live lanes a wave scans cooperatively
     int32_t num_cus;
+    int32_t lds_spheres;    // set by the launcher: sphere planes staged in LDS for the cooperative scan
+    int32_t overdue_priority;
+    uint32_t ray_budget;    // sphere-list kernel: a pixel past this many rays is finished cooperatively
 };
 
 struct KernelInfo {

@@ -416,6 +416,21 @@ static void lower_materials(SceneImpl &s, FlatScene &f)
         r.tex = m.texture ? m.texture - 1 : kNone;
         r.r = m.albedo.x; r.g = m.albedo.y; r.b = m.albedo.z;
         r.p = m.p;
+        if (m.texture) {
+            const HostTexture &t = s.textures[m.texture - 1];
+            auto put = [](double *dst, D3 c) { dst[0] = c.x; dst[1] = c.y; dst[2] = c.z; };
+            if (t.kind == TEX_SOLID) {
+                r.tex_inline = 1;
+                put(r.even, t.color);
+            } else if (t.kind == TEX_CHECKER && s.textures[t.a - 1].kind == TEX_SOLID && s.textures[t.b - 1].kind == TEX_SOLID) {
+                r.tex_inline = 2;
+                put(r.even, s.textures[t.a - 1].color);
+                put(r.odd, s.textures[t.b - 1].color);
+                r.inv_scale = t.s;
+            } else if (t.kind == TEX_CHECKER) {
+                f.flags |= SCENE_RICH_TEXTURES;  // nested checker: general kernel walks the table
+            }
+        }
         // U/V are only ever read by ImageTexture::Value; find out whether this material can reach one
         std::vector<uint32_t> todo;
         if (m.texture) todo.push_back(m.texture);

@@ -175,6 +175,7 @@ def main():
                        "vgprs": st.kernel_vgprs, "lds_bytes": st.lds_bytes},
         }
         bytes_per_ray = None
+        info_spheres = scene.info()["n_spheres"] if world_kind == 1 else 0
         if world == 1 and not args.no_cpu_baseline:
             base, bytes_per_ray, _ = cpu_baseline(wl)
             out["cpu_baseline"] = base
@@ -191,6 +192,15 @@ def main():
                 "note": "algorithmic bytes (SURVEY 8d element sizes x oracle-counted tests per ray) / HIP-event kernel time; "
                         "the tables are chip-resident (scalar cache / L2), so frac may exceed 1: the true limiter is fp64 VALU",
             }
+            if world_kind == 1 and info_spheres:
+                # the limiter: fp64 VALU.  13 fp64 instructions per ray-sphere test (fast build), 4 cycles per wave64
+                # instruction per SIMD, 1024 SIMDs, 2.4 GHz peak clock
+                tests = rays_rank0 * info_spheres
+                out["roofline"]["valu"] = {
+                    "tests_per_s": tests / float(np.mean(kernel_s)),
+                    "peak_tests_per_s": 1024 * 2.4e9 * 64 / (13 * 4),
+                    "frac": tests / float(np.mean(kernel_s)) / (1024 * 2.4e9 * 64 / (13 * 4)),
+                    "unit": "ray-sphere tests/s"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=50, help="diagnostics only (the headline uses the reference's 50)")
     ap.add_argument("--coop-threshold", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--flags", type=int, default=0, help="RT_FLAG_* tuning/diagnostic bits")
+    ap.add_argument("--shade-batch", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--overdue", type=int, default=0, help="tuning knob: rays/sample budget before a pixel goes cooperative")
     args = ap.parse_args()
 
@@ -118,7 +119,7 @@ def main():
     gathered = [torch.empty_like(mine) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
     params = film.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, stream=stream,
-                         coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags)
+                         coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags, shade_batch=args.shade_batch)
 
     def step():
         film.launch(scene, params)

@@ -145,6 +145,8 @@ typedef struct rt_render_params {
     void *stream;                 /* hipStream_t to launch on (NULL = the film's own stream) */
     int32_t coop_threshold;       /* tuning: sphere-list waves with fewer live lanes scan cooperatively (0 = default) */
     int32_t overdue_rays_per_sample; /* tuning: a pixel past this many rays/sample is finished cooperatively (0 = default 8, <0 = never) */
+    int32_t shade_batch;          /* tuning: BVH kernels shade once this many lanes finished traversal (0 = default 16) */
+    int32_t reserved;
 } rt_render_params;
 
 #define RT_FLAG_KEEP_RNG_STATE 1u  /* do not re-seed: continue from the film's saved per-pixel state (progressive) */

@@ -159,6 +159,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.world_kind = f.world_kind;
     d.n_world_items = (uint32_t)f.world_items.size();
     d.n_nodes = (uint32_t)f.nodes.size();
+    d.n_world_nodes = f.n_world_nodes;
     d.n_spheres = (uint32_t)f.spheres.size();
     d.n_mspheres = (uint32_t)f.mspheres.size();
     d.n_quads = (uint32_t)f.quads.size();
@@ -271,6 +272,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 1);
     ra.coop_threshold = p->coop_threshold > 0 ? p->coop_threshold : 24;
     ra.num_cus = f.num_cus;
+    ra.shade_batch = p->shade_batch > 0 ? p->shade_batch : 16;
     ra.overdue_priority = (p->flags & RT_FLAG_OVERDUE_PRIORITY) ? 1 : 0;
     {
         // default budget: 8 rays per sample (about the 98th percentile of the Book-1 scenes)

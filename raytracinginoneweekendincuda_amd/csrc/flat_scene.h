@@ -39,7 +39,9 @@ enum : uint32_t { XF_TRANSLATE = 0u, XF_ROTATE_Y = 1u };
 struct Xform { double a, b, c; uint32_t kind; uint32_t pad; };  // translate: offset xyz; rotate: a = sin, b = cos
 
 // Composite leaf: [ConstantMedium] -> chain of Translate/RotateY (outermost first) -> geometry.
-enum : uint32_t { GEOM_SINGLE = 0u, GEOM_SPHERES = 1u, GEOM_MSPHERES = 2u, GEOM_QUADS = 3u, GEOM_MIXED = 4u };
+enum : uint32_t { GEOM_SINGLE = 0u, GEOM_SPHERES = 1u, GEOM_MSPHERES = 2u, GEOM_QUADS = 3u, GEOM_MIXED = 4u,
+                  GEOM_BVH = 5u };  // GEOM_BVH: `first` = root of a sub-BVH (in nodes[]) over the group's primitives
+constexpr uint32_t kSubBvhMinPrims = 16;  // groups at least this large get a sub-BVH
 struct ObjectRec {
     uint32_t geom_kind;  // GEOM_*
     uint32_t first;      // SINGLE: a prim ref; homogeneous: first prim index; MIXED: first entry of items[]
@@ -104,7 +106,8 @@ struct DeviceScene {
     const CameraRec *camera;
     uint32_t world_kind;
     uint32_t n_world_items;
-    uint32_t n_nodes;
+    uint32_t n_nodes;        // all threaded nodes: the world's first, then sub-BVHs of large groups
+    uint32_t n_world_nodes;
     uint32_t n_spheres, n_mspheres, n_quads, n_objects;
     uint32_t flags;
 };

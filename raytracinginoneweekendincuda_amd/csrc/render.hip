@@ -36,8 +36,9 @@ namespace {
 //              2 = HittableList of static spheres only (config C2: scalar-fed discriminant scan + LDS queue)
 //   COMPOSITE  instances / boxes / lists / media may appear as leaves
 //   RICH       Perlin-noise or image textures may appear
-template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1>
+template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_>
 struct Traits {
+    static constexpr bool MEDIA = MEDIA_;  // ConstantMedium leaves may appear (needs COMPOSITE)
     static constexpr int MIN_WAVES = MIN_WAVES_;  // waves per SIMD the register allocator must leave room for
     static constexpr int WORLD = WORLD_;
     static constexpr bool COMPOSITE = COMPOSITE_;
@@ -210,6 +211,43 @@ DEV Ray to_object_space(const DeviceScene &sc, const ObjectRec &o, const Ray &r)
     return lr;
 }
 
+DEV bool box_test(double xlo, double xhi, double ylo, double yhi, double zlo, double zhi, const Ray &r, Vec inv,
+                  double tmin, double tmax);
+
+// Sub-BVH over a large group's primitives (threaded like the world BVH; nodes stay in global memory / L2).
+DEV bool subbvh_closest(const DeviceScene &sc, uint32_t root, const Ray &lr, double a, double tmin, double tmax,
+                        double &t_best, uint32_t &ref_best)
+{
+    Vec inv = mk(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
+    double closest = tmax;
+    bool any = false;
+    uint32_t n = root;
+    while (n != kNone) {
+        BvhNodeRec node = sc.nodes[n];
+        uint32_t next = node.escape;
+        if (box_test(node.xlo, node.xhi, node.ylo, node.yhi, node.zlo, node.zhi, lr, inv, tmin, closest)) {
+            if ((node.a >> kRefShift) == REF_INNER) {
+                next = n + 1;
+            } else {
+                double t;
+                if (prim_test(sc, node.a, lr, a, tmin, closest, t)) {
+                    any = true;
+                    closest = t;
+                    ref_best = node.a;
+                }
+                if (node.b != node.a && prim_test(sc, node.b, lr, a, tmin, closest, t)) {
+                    any = true;
+                    closest = t;
+                    ref_best = node.b;
+                }
+            }
+        }
+        n = next;
+    }
+    t_best = closest;
+    return any;
+}
+
 // Closest hit over a composite leaf's geometry (R/HittableList.h:39-57 for groups).
 DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, double tmin, double tmax,
                       double &t_best, uint32_t &ref_best)
@@ -217,6 +255,7 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
     double a = dot(lr.d, lr.d);
     bool any = false;
     double closest = tmax;
+    if (o.geom_kind == GEOM_BVH) return subbvh_closest(sc, o.first, lr, a, tmin, tmax, t_best, ref_best);
     switch (o.geom_kind) {
     case GEOM_SINGLE: {
         double t;
@@ -276,23 +315,30 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
 }
 
 // Composite leaf: instance chain and, for media, the stochastic volume hit (R/ConstantMedium.h:52-94).
+template <class T>
 DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng)
 {
     ObjectRec o = sc.objects[oi];
     Ray lr = to_object_space(sc, o, r);
-    if (o.medium == kNone) {
+    // surfaces: one closest-hit query over [tmin, tmax]; media: two boundary queries (R/ConstantMedium.h:58-64)
+    const bool medium = T::MEDIA && o.medium != kNone;
+    double t1 = 0.0, t2 = 0.0;
+    uint32_t pref = kNone;
+    for (int pass = 0; pass < 2; pass++) {  // one inlined copy of the geometry query
+        const double lo = medium ? (pass == 0 ? -DBL_MAX : t1 + 0.0001) : tmin;
+        const double hi = medium ? DBL_MAX : tmax;
         double t;
-        uint32_t pref;
-        if (!geom_closest(sc, o, lr, tmin, tmax, t, pref)) return false;
-        best.t = t;
+        if (!geom_closest(sc, o, lr, lo, hi, t, pref)) return false;
+        if (pass == 0) t1 = t;
+        else t2 = t;
+        if (!medium) break;
+    }
+    if (!medium) {
+        best.t = t1;
         best.ref = pref;
         best.obj = oi;
         return true;
     }
-    double t1, t2;
-    uint32_t unused;
-    if (!geom_closest(sc, o, lr, -DBL_MAX, DBL_MAX, t1, unused)) return false;
-    if (!geom_closest(sc, o, lr, t1 + 0.0001, DBL_MAX, t2, unused)) return false;
     if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
@@ -314,7 +360,7 @@ template <class T>
 DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng)
 {
     if constexpr (T::COMPOSITE) {
-        if ((ref >> kRefShift) == REF_OBJECT) return object_test(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
+        if ((ref >> kRefShift) == REF_OBJECT) return object_test<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
     }
     double t;
     if (!prim_test(sc, ref, r, a, tmin, tmax, t)) return false;
@@ -351,49 +397,58 @@ DEV bool box_test(double xlo, double xhi, double ylo, double yhi, double zlo, do
 }
 
 // Stackless walk in the reference's visiting order (R/BvhNode.h:101-158): a node's leaf children are
-// tested where the node is visited; "pop" is the escape link.
-template <class T>
-DEV bool world_hit_bvh(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng)
+// tested where the node is visited; "pop" is the escape link.  The walk is resumable: a lane keeps its
+// position (node index, closest hit so far) in registers, so that the kernel can interleave traversal
+// bursts with shading and never makes 63 lanes wait for the one ray that visits 150 nodes.
+struct Walk {
+    Vec inv;          // 1 / direction (R/AABB.h:77,84,91 recompute it per node; same value)
+    double a;         // dot(d, d)
+    double closest;
+    uint32_t node;    // next node to visit; kNone = finished
+    bool any;
+};
+
+DEV void walk_begin(Walk &w, const Ray &r, double tmax)
 {
-    Vec inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
-    double a = dot(r.d, r.d);
-    double closest = tmax;
-    bool any = false;
-    uint32_t n = 0;
-    while (n != kNone) {
-        double xlo, xhi, ylo, yhi, zlo, zhi;
-        uint32_t na, nb, next;
-        if (nv.in_lds) {
-            xlo = nv.xlo[n]; xhi = nv.xhi[n]; ylo = nv.ylo[n]; yhi = nv.yhi[n]; zlo = nv.zlo[n]; zhi = nv.zhi[n];
-            na = nv.a[n]; nb = nv.b[n]; next = nv.escape[n];
+    w.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    w.a = dot(r.d, r.d);
+    w.closest = tmax;
+    w.node = 0;
+    w.any = false;
+}
+
+template <class T>
+DEV void walk_step(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng)
+{
+    const uint32_t n = w.node;
+    double xlo, xhi, ylo, yhi, zlo, zhi;
+    uint32_t na, nb, next;
+    if (nv.in_lds) {
+        xlo = nv.xlo[n]; xhi = nv.xhi[n]; ylo = nv.ylo[n]; yhi = nv.yhi[n]; zlo = nv.zlo[n]; zhi = nv.zhi[n];
+        na = nv.a[n]; nb = nv.b[n]; next = nv.escape[n];
+    } else {
+        BvhNodeRec node = nv.global[n];
+        xlo = node.xlo; xhi = node.xhi; ylo = node.ylo; yhi = node.yhi; zlo = node.zlo; zhi = node.zhi;
+        na = node.a; nb = node.b; next = node.escape;
+    }
+    if (box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest)) {
+        if ((na >> kRefShift) == REF_INNER) {
+            next = n + 1;
         } else {
-            BvhNodeRec node = nv.global[n];
-            xlo = node.xlo; xhi = node.xhi; ylo = node.ylo; yhi = node.yhi; zlo = node.zlo; zhi = node.zhi;
-            na = node.a; nb = node.b; next = node.escape;
-        }
-        if (box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, inv, tmin, closest)) {
-            if ((na >> kRefShift) == REF_INNER) {
-                next = n + 1;
-            } else {
-                if (leaf_test<T>(sc, na, r, a, tmin, closest, best, rng)) {
-                    any = true;
-                    closest = best.t;
-                }
-                // span-1 nodes hold the same leaf twice (R/BvhNode.h:63-67).  Re-testing a surface with
-                // tmax = its own t changes nothing; a medium draws again, so only media are re-tested.
-                bool again = nb != na;
-                if constexpr (T::COMPOSITE) again = again || is_medium_leaf(sc, nb);
-                if (again) {
-                    if (leaf_test<T>(sc, nb, r, a, tmin, closest, best, rng)) {
-                        any = true;
-                        closest = best.t;
-                    }
+            // span-1 nodes hold the same leaf twice (R/BvhNode.h:63-67).  Re-testing a surface with
+            // tmax = its own t changes nothing; a medium draws again, so only media are re-tested.
+            bool again = nb != na;
+            if constexpr (T::MEDIA) again = again || is_medium_leaf(sc, nb);
+            for (int c = 0; c < 2; c++) {  // one inlined copy of the leaf test
+                if (c == 1 && !again) break;
+                if (leaf_test<T>(sc, c ? nb : na, r, w.a, tmin, w.closest, best, rng)) {
+                    w.any = true;
+                    w.closest = best.t;
                 }
             }
         }
-        n = next;
     }
-    return any;
+    w.node = next;
 }
 
 // HittableList world (R/HittableList.h:39-57): the item index is wave-uniform, so the primitive rows
@@ -423,6 +478,7 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
 //     running closest-so-far -- the same order the reference's loop meets those spheres in.
 constexpr int kQueueCap = 12;   // entries per lane; the queue is drained whenever a lane could overflow
 constexpr int kScanUnroll = 4;
+constexpr int kBurst = 8;       // BVH worlds: node visits per traversal burst
 
 DEV void drain_queue(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
                      const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
@@ -643,7 +699,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
     s.u = 0.0;
     s.v = 0.0;
     uint32_t tag = h.ref >> kRefShift, idx = h.ref & kRefIndexMask;
-    if constexpr (T::COMPOSITE) {
+    if constexpr (T::MEDIA) {
         if (tag == REF_MEDIUM) {  // R/ConstantMedium.h:86-91
             s.p = at(r, h.t);
             s.n = mk(1, 0, 0);
@@ -711,18 +767,19 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
 // ------------------------------------------------------------------------------------------------
 // textures and materials
 // ------------------------------------------------------------------------------------------------
-__device__ __noinline__ double perlin_noise(const PerlinRec *pn, Vec p)  // R/Perlin.h:38-60,120-139
+DEV double perlin_noise(const PerlinRec *pn, Vec p)  // R/Perlin.h:38-60,120-139
 {
     double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
     double u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
     double uu = u * u * (3.0 - 2.0 * u), vv = v * v * (3.0 - 2.0 * v), ww = w * w * (3.0 - 2.0 * w);
     double accum = 0.0;
-#pragma unroll
+    // corners one after another (same summation order as the reference; keeps the register footprint small)
+#pragma unroll 1
     for (int a = 0; a < 2; a++)
-#pragma unroll
+#pragma unroll 1
         for (int b = 0; b < 2; b++)
-#pragma unroll
+#pragma unroll 1
             for (int c = 0; c < 2; c++) {
                 int idx = pn->perm_x[(i + a) & 255] ^ pn->perm_y[(j + b) & 255] ^ pn->perm_z[(k + c) & 255];
                 Vec g = mk(pn->vec[idx][0], pn->vec[idx][1], pn->vec[idx][2]);
@@ -776,15 +833,17 @@ DEV Vec texture_value(const DeviceScene &sc, uint32_t ti, double u, double v, Ve
 
 // Texture of a material: host-resolved solid / checker-of-solids without touching the texture table.
 template <class T>
-DEV Vec material_texture(const DeviceScene &sc, const MaterialRec &m, double u, double v, Vec p)
+DEV Vec material_texture(const DeviceScene &sc, const MaterialRec *m, uint32_t tex_inline, double u, double v, Vec p)
 {
-    if (m.tex_inline == 1) return mk(m.even[0], m.even[1], m.even[2]);
-    if (m.tex_inline == 2) {  // R/Texture.h:70-81
-        int xi = (int)floor(m.inv_scale * p.x), yi = (int)floor(m.inv_scale * p.y), zi = (int)floor(m.inv_scale * p.z);
+    if (tex_inline == 1) return mk(m->even[0], m->even[1], m->even[2]);
+    if (tex_inline == 2) {  // R/Texture.h:70-81
+        const double inv_scale = m->inv_scale;
+        int xi = (int)floor(inv_scale * p.x), yi = (int)floor(inv_scale * p.y), zi = (int)floor(inv_scale * p.z);
         bool even = ((xi + yi + zi) % 2) == 0;
-        return even ? mk(m.even[0], m.even[1], m.even[2]) : mk(m.odd[0], m.odd[1], m.odd[2]);
+        const double *c = even ? m->even : m->odd;
+        return mk(c[0], c[1], c[2]);
     }
-    if constexpr (T::RICH) return texture_value<T>(sc, m.tex, u, v, p);
+    if constexpr (T::RICH) return texture_value<T>(sc, m->tex, u, v, p);
     return mk(0.0, 0.0, 0.0);  // unreachable: scenes with table-walking textures run the RICH instantiation
 }
 
@@ -807,7 +866,9 @@ DEV Vec random_in_unit_sphere(Xorwow &rng)  // R/Material.h:14-24
 template <class T>
 DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughput, Vec &accumulated, Xorwow &rng)
 {
-    const MaterialRec m = sc.materials[s.mat];
+    // only the fields a material kind needs are loaded (the row is 112 bytes)
+    const MaterialRec *mp = sc.materials + s.mat;
+    struct { uint32_t kind, tex_inline; } m = {mp->kind, mp->tex_inline};
     Vec atten;
     Ray out;
     out.o = s.p;
@@ -817,25 +878,26 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
     if (m.kind == MAT_METAL || m.kind == MAT_DIELECTRIC) ud = unit(ray.d);
     switch (m.kind) {
     case MAT_DIFFUSE_LIGHT:  // R/Material.h:114-127: emits on both sides, never scatters
-        accumulated = accumulated + throughput * material_texture<T>(sc, m, s.u, s.v, s.p);
+        accumulated = accumulated + throughput * material_texture<T>(sc, mp, m.tex_inline, s.u, s.v, s.p);
         return false;
     case MAT_LAMBERTIAN: {  // R/Material.h:67-82
         Vec dir = s.n + rs;
         if (fabs(dir.x) < 1e-8 && fabs(dir.y) < 1e-8 && fabs(dir.z) < 1e-8) dir = s.n;
         out.d = dir;
-        atten = material_texture<T>(sc, m, s.u, s.v, s.p);
+        atten = material_texture<T>(sc, mp, m.tex_inline, s.u, s.v, s.p);
         break;
     }
     case MAT_METAL: {  // R/Metal.h:18-30
         Vec refl = reflect(ud, s.n);
-        out.d = refl + m.p * rs;
-        atten = mk(m.r, m.g, m.b);
+        out.d = refl + mp->p * rs;
+        atten = mk(mp->r, mp->g, mp->b);
         if (!(dot(out.d, s.n) > 0.0)) return false;
         break;
     }
     case MAT_DIELECTRIC: {  // R/Dielectric.h:18-68
         atten = mk(1.0, 1.0, 1.0);
-        double ratio = s.front ? (1.0 / m.p) : m.p;
+        const double ior = mp->p;
+        double ratio = s.front ? (1.0 / ior) : ior;
         double ct = fmin(dot(-ud, s.n), 1.0);
         double st = sqrt(1.0 - ct * ct);
         bool reflect_it = ratio * st > 1.0;
@@ -850,7 +912,7 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
     }
     default: {  // MAT_ISOTROPIC, R/Material.h:152-163
         out.d = unit(rs);
-        atten = material_texture<T>(sc, m, s.u, s.v, s.p);
+        atten = material_texture<T>(sc, mp, m.tex_inline, s.u, s.v, s.p);
         break;
     }
     }
@@ -928,7 +990,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         nv.global = sc.nodes;
         nv.in_lds = a.lds_nodes != 0;
         if (nv.in_lds) {
-            const uint32_t n = sc.n_nodes;
+            const uint32_t n = sc.n_world_nodes;
             double *planes = reinterpret_cast<double *>(lds_raw);
             uint32_t *words = reinterpret_cast<uint32_t *>(planes + 6 * (size_t)n);
             for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
@@ -982,6 +1044,13 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     uint32_t nrays = 0;
 
     uint32_t pix_rays = 0;  // rays this lane's current pixel has traced so far
+    // BVH worlds: per-lane resumable traversal (see Walk) and the hit it has found so far
+    Walk walk{};
+    HitInfo walk_best;
+    walk_best.t = 0.0;
+    walk_best.ref = kNone;
+    walk_best.obj = kNone;
+    bool walking = false;
 
     for (;;) {
         // A pixel that has used up its ray budget is "overdue": its samples cannot be spread over lanes (one
@@ -1028,6 +1097,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         pix_rays = 0;
                         ray = camera_ray(cam, i, j, a.width, a.height, rng);
                         active = true;
+                        if constexpr (T::WORLD == 0) {
+                            walk_begin(walk, ray, DBL_MAX);
+                            walking = true;
+                        }
                     }
                 }
             }
@@ -1053,11 +1126,27 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 scan_cooperative(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
             }
         }
+        if constexpr (T::WORLD == 0) {
+            // Traversal burst: every walking lane advances up to kBurst nodes.  Lanes whose walk is complete
+            // wait for shading; they are shaded once enough of them have gathered (or nobody is walking any
+            // more), then start their next ray and rejoin the walkers.
+            for (int step = 0; step < kBurst; step++) {
+                if (walking) {
+                    walk_step<T>(sc, nv, ray, 0.001, walk, walk_best, rng);
+                    walking = walk.node != kNone;
+                }
+            }
+            const unsigned long long walkers = __ballot(walking);
+            const unsigned long long waiting = live & ~walkers;
+            const int n_wait = __popcll(waiting), n_walk = __popcll(walkers);
+            todo = (n_wait >= a.shade_batch || n_wait >= n_walk) ? waiting : 0ull;
+            hit = walk.any;
+            h = walk_best;
+        }
         if ((todo >> lane) & 1ull) {
             nrays++;
             pix_rays++;
-            if constexpr (T::WORLD == 0) hit = world_hit_bvh<T>(sc, nv, ray, 0.001, DBL_MAX, h, rng);
-            else if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng);
+            if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng);
             bool path_ends;
             if (!hit) {  // R/kernel.cu:74-79
                 accumulated = accumulated + throughput * load3c(((const RT_CONST CameraRec *)(uintptr_t)cam)->bg);
@@ -1089,6 +1178,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                     active = false;
                 }
             }
+            if constexpr (T::WORLD == 0) {
+                if (active) {
+                    walk_begin(walk, ray, DBL_MAX);
+                    walking = true;
+                }
+            }
         }
     }
 
@@ -1116,15 +1211,20 @@ hipError_t RT_CAT(launch_seed_, RT_SUFFIX)(const SeedArgs &a, hipStream_t stream
 
 namespace {
 #ifndef RT_WAVES_SPHERES
-#define RT_WAVES_SPHERES 3
+#define RT_WAVES_SPHERES 2
 #endif
 #ifndef RT_WAVES_BVH
 #define RT_WAVES_BVH 3
 #endif
 using TSphereList = Traits<2, false, false, RT_WAVES_SPHERES>;
 using TBvhPrims = Traits<0, false, false, RT_WAVES_BVH>;
-using TBvhGeneral = Traits<0, true, true>;
-using TListGeneral = Traits<1, true, true>;
+#ifndef RT_WAVES_GENERAL
+#define RT_WAVES_GENERAL 2
+#endif
+using TBvhGeneral = Traits<0, true, true, RT_WAVES_GENERAL>;
+using TListGeneral = Traits<1, true, true, RT_WAVES_GENERAL>;
+using TBvhInstances = Traits<0, true, false, RT_WAVES_GENERAL, false>;  // instances / boxes, no media, plain textures (C4)
+using TBvhMedia = Traits<0, true, false, RT_WAVES_GENERAL, true>;       // + ConstantMedium (Cornell smoke)
 
 template <class T>
 hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, KernelInfo *info)
@@ -1134,7 +1234,7 @@ hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, K
     size_t lds = 0;
     a.lds_nodes = 0;
     if (T::WORLD == 0) {
-        size_t need = (size_t)sc.n_nodes * (6 * sizeof(double) + 3 * sizeof(uint32_t));
+        size_t need = (size_t)sc.n_world_nodes * (6 * sizeof(double) + 3 * sizeof(uint32_t));
         if (need <= 60 * 1024) {  // keep >= 2 workgroups per CU resident
             lds = need;
             a.lds_nodes = 1;
@@ -1154,7 +1254,7 @@ hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, K
         if (e != hipSuccess) return e;
         info->vgprs = attr.numRegs;
         info->lds_bytes = (int)(attr.sharedSizeBytes + lds);
-        info->kind = T::WORLD * 4 + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0);
+        info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0);
         return hipSuccess;
     }
     if (a.n_pixels == 0 || a.spp <= 0) return hipSuccess;
@@ -1179,6 +1279,10 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
         return launch_one<TSphereList>(sc, a, stream, info);
     if (sc.world_kind == WORLD_BVH) {
         if (!composite && !rich && !a.force_general) return launch_one<TBvhPrims>(sc, a, stream, info);
+        if (!rich && !a.force_general) {
+            if (!(sc.flags & SCENE_HAS_MEDIA)) return launch_one<TBvhInstances>(sc, a, stream, info);
+            return launch_one<TBvhMedia>(sc, a, stream, info);
+        }
         return launch_one<TBvhGeneral>(sc, a, stream, info);
     }
     return launch_one<TListGeneral>(sc, a, stream, info);

@@ -244,6 +244,13 @@ struct Flattener {
     SceneImpl &s;
     FlatScene &f;
     std::string err;
+    // sub-BVHs are emitted after the world's nodes (the kernel stages nodes [0, n_world_nodes) in LDS)
+    struct PendingSubBvh {
+        uint32_t object;
+        HostHittable tree;
+        std::vector<uint32_t> ref_of;
+    };
+    std::vector<PendingSubBvh> pending;
 
     uint32_t add_primitive(const HostHittable &h)
     {
@@ -337,7 +344,20 @@ struct Flattener {
                 all_q &= k == HKind::Quad;
             }
             obj.count = (uint32_t)prims.size();
-            if (prims.empty()) {
+            if (prims.size() >= kSubBvhMinPrims) {
+                // A closest-hit scan and a BVH over the same primitives return the same hit (the reference's own
+                // invariant, Docs 2-3 BVH :733,:772); primitives draw no random numbers, so nothing else changes.
+                HostHittable sub{};
+                sub.kind = HKind::Bvh;
+                std::vector<uint32_t> objs = prims;
+                build_tree(&s, sub, objs, 0, (int)objs.size());
+                std::vector<uint32_t> ref_of(s.hittables.size() + 1, kNone);
+                for (uint32_t hnd : objs)
+                    if (ref_of[hnd] == kNone) ref_of[hnd] = add_primitive(s.hittables[hnd - 1]);
+                obj.geom_kind = GEOM_BVH;
+                obj.first = kNone;  // patched by emit_pending()
+                pending.push_back({(uint32_t)f.objects.size(), std::move(sub), std::move(ref_of)});
+            } else if (prims.empty()) {
                 obj.geom_kind = GEOM_MIXED;
                 obj.first = (uint32_t)f.items.size();
             } else if (all_s || all_m || all_q) {
@@ -355,6 +375,12 @@ struct Flattener {
         }
         f.objects.push_back(obj);
         return make_ref(REF_OBJECT, (uint32_t)f.objects.size() - 1);
+    }
+
+    void emit_pending()
+    {
+        for (auto &job : pending) f.objects[job.object].first = thread_tree(job.tree, 0, kNone, job.ref_of);
+        pending.clear();
     }
 
     // Thread the reference's traversal (R/BvhNode.h:101-158) into escape links.  The reference visits
@@ -490,11 +516,13 @@ int flatten_scene(SceneImpl &s)
     if (f.world_kind == WORLD_BVH) {
         if (world.tree.empty()) return fail(RT_ERR_INVALID, "BvhNode world has no nodes");
         fl.thread_tree(world, 0, kNone, ref_of_handle);
+        f.n_world_nodes = (uint32_t)f.nodes.size();
     } else {
         bool all_spheres = !f.world_items.empty();
         for (size_t k = 0; k < f.world_items.size(); k++) all_spheres &= f.world_items[k] == make_ref(REF_SPHERE, (uint32_t)k);
         if (all_spheres && f.spheres.size() == f.world_items.size()) f.flags |= SCENE_LIST_ALL_SPHERES;
     }
+    fl.emit_pending();
     s.committed = true;
     return RT_OK;
 }

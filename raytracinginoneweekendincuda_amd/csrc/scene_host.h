@@ -77,6 +77,7 @@ struct FlatScene {
     std::vector<PerlinRec> perlin;
     uint32_t world_kind = WORLD_BVH;
     uint32_t flags = 0;
+    uint32_t n_world_nodes = 0;
 };
 
 struct DeviceTables;  // device_scene.cpp

@@ -406,6 +406,7 @@ struct Walk {
     double closest;
     uint32_t node;    // next node to visit; kNone = finished
     bool any;
+    bool at_leaves;   // standing on a bottom node whose box was hit: its leaves are tested in the next leaf phase
 };
 
 DEV void walk_begin(Walk &w, const Ray &r, double tmax)
@@ -415,40 +416,58 @@ DEV void walk_begin(Walk &w, const Ray &r, double tmax)
     w.closest = tmax;
     w.node = 0;
     w.any = false;
+    w.at_leaves = false;
 }
 
-template <class T>
-DEV void walk_step(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng)
+// One inner-node step: box test, then descend / escape; a bottom node whose box is hit parks the lane.
+DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
 {
     const uint32_t n = w.node;
     double xlo, xhi, ylo, yhi, zlo, zhi;
-    uint32_t na, nb, next;
+    uint32_t na, next;
     if (nv.in_lds) {
         xlo = nv.xlo[n]; xhi = nv.xhi[n]; ylo = nv.ylo[n]; yhi = nv.yhi[n]; zlo = nv.zlo[n]; zhi = nv.zhi[n];
-        na = nv.a[n]; nb = nv.b[n]; next = nv.escape[n];
+        na = nv.a[n]; next = nv.escape[n];
     } else {
-        BvhNodeRec node = nv.global[n];
-        xlo = node.xlo; xhi = node.xhi; ylo = node.ylo; yhi = node.yhi; zlo = node.zlo; zhi = node.zhi;
-        na = node.a; nb = node.b; next = node.escape;
+        const BvhNodeRec *node = nv.global + n;
+        xlo = node->xlo; xhi = node->xhi; ylo = node->ylo; yhi = node->yhi; zlo = node->zlo; zhi = node->zhi;
+        na = node->a; next = node->escape;
     }
     if (box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest)) {
-        if ((na >> kRefShift) == REF_INNER) {
-            next = n + 1;
-        } else {
-            // span-1 nodes hold the same leaf twice (R/BvhNode.h:63-67).  Re-testing a surface with
-            // tmax = its own t changes nothing; a medium draws again, so only media are re-tested.
-            bool again = nb != na;
-            if constexpr (T::MEDIA) again = again || is_medium_leaf(sc, nb);
-            for (int c = 0; c < 2; c++) {  // one inlined copy of the leaf test
-                if (c == 1 && !again) break;
-                if (leaf_test<T>(sc, c ? nb : na, r, w.a, tmin, w.closest, best, rng)) {
-                    w.any = true;
-                    w.closest = best.t;
-                }
-            }
+        if ((na >> kRefShift) == REF_INNER) next = n + 1;
+        else {
+            w.at_leaves = true;
+            return;  // stay on this node until the leaf phase
         }
     }
     w.node = next;
+}
+
+// Leaf phase for a parked lane: the bottom node's one or two leaves, in the reference's order.
+template <class T>
+DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng)
+{
+    const uint32_t n = w.node;
+    uint32_t na, nb, next;
+    if (nv.in_lds) {
+        na = nv.a[n]; nb = nv.b[n]; next = nv.escape[n];
+    } else {
+        const BvhNodeRec *node = nv.global + n;
+        na = node->a; nb = node->b; next = node->escape;
+    }
+    // span-1 nodes hold the same leaf twice (R/BvhNode.h:63-67).  Re-testing a surface with
+    // tmax = its own t changes nothing; a medium draws again, so only media are re-tested.
+    bool again = nb != na;
+    if constexpr (T::MEDIA) again = again || is_medium_leaf(sc, nb);
+    for (int c = 0; c < 2; c++) {  // one inlined copy of the leaf test
+        if (c == 1 && !again) break;
+        if (leaf_test<T>(sc, c ? nb : na, r, w.a, tmin, w.closest, best, rng)) {
+            w.any = true;
+            w.closest = best.t;
+        }
+    }
+    w.node = next;
+    w.at_leaves = false;
 }
 
 // HittableList world (R/HittableList.h:39-57): the item index is wave-uniform, so the primitive rows
@@ -478,7 +497,8 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
 //     running closest-so-far -- the same order the reference's loop meets those spheres in.
 constexpr int kQueueCap = 12;   // entries per lane; the queue is drained whenever a lane could overflow
 constexpr int kScanUnroll = 4;
-constexpr int kBurst = 8;       // BVH worlds: node visits per traversal burst
+constexpr int kBurst = 8;       // BVH worlds: at most this many node visits between two leaf phases
+constexpr int kRounds = 4;      // node/leaf phase pairs per look at the shading queue
 
 DEV void drain_queue(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
                      const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
@@ -1130,11 +1150,24 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             // Traversal burst: every walking lane advances up to kBurst nodes.  Lanes whose walk is complete
             // wait for shading; they are shaded once enough of them have gathered (or nobody is walking any
             // more), then start their next ray and rejoin the walkers.
-            for (int step = 0; step < kBurst; step++) {
-                if (walking) {
-                    walk_step<T>(sc, nv, ray, 0.001, walk, walk_best, rng);
+            // Inner nodes and leaves run in separate phases so that the (long, branchy) leaf tests execute with
+            // many lanes at once instead of trailing every node visit with a few.
+            for (int round = 0; round < kRounds; round++) {
+                for (int step = 0; step < kBurst; step++) {
+                    const bool mover = walking && !walk.at_leaves;
+                    const int movers = __popcll(__ballot(mover));
+                    const int parked = __popcll(__ballot(walking && walk.at_leaves));
+                    if (movers == 0 || movers < parked) break;  // most walkers are waiting at leaves: go test them
+                    if (mover) {
+                        walk_node(nv, ray, 0.001, walk);
+                        walking = walk.node != kNone;
+                    }
+                }
+                if (walking && walk.at_leaves) {
+                    walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng);
                     walking = walk.node != kNone;
                 }
+                if (!__any(walking)) break;
             }
             const unsigned long long walkers = __ballot(walking);
             const unsigned long long waiting = live & ~walkers;

@@ -70,6 +70,16 @@ def cpu_baseline(wl, budget_s=12.0):
     }, bytes_per_ray, stats["rays"] / samples
 
 
+def measured_traffic(workload, spp, variant):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (FETCH_SIZE x2 +
+    WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); only valid for the exact configuration profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_v4_c2_pmc.json")
+    if workload != "c2" or spp != 500 or variant != "fast" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,7 +198,7 @@ def main():
             achieved = bytes_per_ray * rays_rank0 / float(np.mean(kernel_s)) * 1e-9
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args.workload, spp, args.variant),
                 "algorithmic_bytes_per_ray": bytes_per_ray,
                 "note": "algorithmic bytes (SURVEY 8d element sizes x oracle-counted tests per ray) / HIP-event kernel time; "
                         "the tables are chip-resident (scalar cache / L2), so frac may exceed 1: the true limiter is fp64 VALU",

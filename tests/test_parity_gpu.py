@@ -119,3 +119,64 @@ def test_ppm_bytes_match_oracle_writer(oracle, tmp_path):
     oracle.L.oracle_write_ppm(str(b).encode(), frame.ctypes.data, 32, 16)
     assert a.read_bytes() == b.read_bytes()
     assert a.read_bytes().startswith(b"P3\n32 16\n255\n")
+
+
+# ---- scheduling variants must not change a single bit ----
+def _render(scene_id, world, **kw):
+    s = rt.builtin_scene(scene_id, world, W, H)
+    return s.render(W, H, SPP, variant=0, **kw)
+
+
+@pytest.mark.parametrize("scene_id,world_kind", [(11, 1), (10, 1)])
+def test_cooperative_scan_equals_pixel_parallel_scan(scene_id, world_kind):
+    """Sphere-list kernel: the ray-cooperative scan (64 lanes split one ray's spheres, DPP min over (t, k))
+    returns the same hit as the per-lane sequential scan -- for every ray, not just in the frame tail."""
+    ref, st0 = _render(scene_id, world_kind, coop_threshold=1, overdue=-1)       # never cooperative
+    allc, st1 = _render(scene_id, world_kind, coop_threshold=65, overdue=-1)     # always cooperative
+    over, st2 = _render(scene_id, world_kind, coop_threshold=1, overdue=1)       # pixels go cooperative after 1 ray/sample
+    assert st0.kernel_kind == 16, "expected the sphere-list instantiation"
+    assert np.array_equal(ref.view(np.uint64), allc.view(np.uint64))
+    assert np.array_equal(ref.view(np.uint64), over.view(np.uint64))
+    assert st0.rays == st1.rays == st2.rays
+
+
+@pytest.mark.parametrize("scene_id,world_kind", [(11, 1), (0, 0), (4, 0), (7, 0), (8, 0)])
+def test_specialised_kernels_equal_general_kernel(scene_id, world_kind):
+    fast_path, st0 = _render(scene_id, world_kind)
+    general, st1 = _render(scene_id, world_kind, flags=2)  # RT_FLAG_FORCE_GENERAL
+    assert st0.kernel_kind != st1.kernel_kind
+    assert np.array_equal(fast_path.view(np.uint64), general.view(np.uint64))
+
+
+@pytest.mark.parametrize("batch", [1, 64])
+def test_bvh_shading_batch_does_not_change_results(batch):
+    a, _ = _render(0, 0)
+    b, _ = _render(0, 0, shade_batch=batch)
+    c, _ = _render(9, 0, shade_batch=batch)
+    d, _ = _render(9, 0)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert np.array_equal(c.view(np.uint64), d.view(np.uint64))
+
+
+def test_sub_bvh_group_equals_linear_group():
+    """a large HittableList inside an instance gets a sub-BVH; 15 spheres stay a linear scan.
+    Same spheres, two encodings -> same picture."""
+    def build(n_extra):
+        s = rt.Scene()
+        white = s.Lambertian((0.73, 0.73, 0.73))
+        rng = np.random.default_rng(5)
+        pts = rng.uniform(0, 4, size=(15, 3))
+        balls = [s.Sphere(tuple(p), 0.35, white) for p in pts]
+        # far-away filler spheres (never hit) push the group over the sub-BVH threshold
+        balls += [s.Sphere((1000.0 + 3 * k, 1000.0, 1000.0), 0.1, white) for k in range(n_extra)]
+        grp = s.Translate(s.RotateY(s.HittableList(balls), 20.0), (-2.0, -2.0, -6.0))
+        floor = s.Quad((-20, -3, -20), (40, 0, 0), (0, 0, 40), s.Lambertian((0.4, 0.6, 0.4)))
+        s.SetWorld(s.HittableList([grp, floor]))
+        s.Camera((0, 0, 3), (0, 0, -4), (0, 1, 0), 50, W / H, 0.0, 10.0)
+        s.Commit()
+        return s
+    lin, few = build(0), build(40)
+    assert lin.info()["n_nodes"] == 0 and few.info()["n_nodes"] > 0
+    a, _ = lin.render(W, H, SPP, variant=0)
+    b, _ = few.render(W, H, SPP, variant=0)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))

@@ -63,6 +63,10 @@ RTOW_API rt_handle rt_checker_texture(rt_scene *s, double scale, rt_handle even,
 /* bytes are copied; w*h*3 RGB, row 0 = top (what RtwImage hands to ImageTexture, R/RtwImage.h:51-92). NULL data => cyan. */
 RTOW_API rt_handle rt_image_texture(rt_scene *s, const unsigned char *rgb, int width, int height); /* :103 */
 RTOW_API rt_handle rt_noise_texture(rt_scene *s, double scale, rt_rng *rng);                  /* :153; draws from rng */
+/* What RtwImage::Load does to decoded 8-bit pixels before ImageTexture sees them (R/RtwImage.h:54,66-67,100-105 on top
+ * of stbi_loadf's LDR->HDR step, R/external/stb_image.h:1869): out = FloatToByte((float)pow(in / 255.0f, 2.2f)).
+ * JPEG decoding itself is the caller's (any decoder; stb's may differ from it by +-1 per byte). in/out may alias. */
+RTOW_API void rt_rtwimage_bytes(const unsigned char *decoded_srgb, size_t count, unsigned char *out);
 
 /* ---- materials (R/Material.h, R/Metal.h, R/Dielectric.h) ---- */
 RTOW_API rt_handle rt_lambertian(rt_scene *s, double r, double g, double b);                  /* Material.h:57 */

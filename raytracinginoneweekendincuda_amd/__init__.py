@@ -15,11 +15,13 @@ from .api import (  # noqa: F401
     stripe_rows,
     deinterleave,
     write_ppm,
+    rtwimage_bytes,
+    load_image,
     library_path,
     lib,
 )
 
 __all__ = [
     "RtowError", "Rng", "Scene", "Film", "RenderParams", "RenderStats", "builtin_scene",
-    "stripe_rows", "deinterleave", "write_ppm", "library_path", "lib",
+    "stripe_rows", "deinterleave", "write_ppm", "rtwimage_bytes", "load_image", "library_path", "lib",
 ]

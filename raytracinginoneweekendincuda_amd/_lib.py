@@ -53,6 +53,7 @@ SIGNATURES = {
     "rt_checker_texture": (H, [P, D, H, H]),
     "rt_image_texture": (H, [P, P, I, I]),
     "rt_noise_texture": (H, [P, D, P]),
+    "rt_rtwimage_bytes": (None, [P, C.c_size_t, P]),
     "rt_lambertian": (H, [P, D, D, D]),
     "rt_lambertian_tex": (H, [P, H]),
     "rt_metal": (H, [P, D, D, D, D]),

@@ -275,6 +275,27 @@ class Film:
         return frame
 
 
+def rtwimage_bytes(decoded_rgb):
+    """RtwImage::Load's pixel conversion (stb linearisation with gamma 2.2, then FloatToByte): takes decoded 8-bit
+    sRGB pixels (H, W, 3) from any JPEG decoder and returns the bytes the reference hands to ImageTexture."""
+    a = np.ascontiguousarray(decoded_rgb, dtype=np.uint8)
+    out = np.empty_like(a)
+    lib().rt_rtwimage_bytes(a.ctypes.data, a.size, out.ctypes.data)
+    return out
+
+
+def load_image(path):
+    """Decode an image file with Pillow and apply rtwimage_bytes (R/RtwImage.h:51-87).  Returns None if the
+    file cannot be read, which ImageTexture turns into the reference's cyan fallback."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            rgb = np.asarray(im.convert("RGB"))
+    except Exception:
+        return None
+    return rtwimage_bytes(rgb)
+
+
 def stripe_rows(height, stripe, rank, world_size):
     n = lib().rt_stripe_rows(height, stripe, rank, world_size, None, 0)
     if n < 0:

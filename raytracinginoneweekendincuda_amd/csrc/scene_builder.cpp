@@ -609,6 +609,18 @@ rt_handle rt_image_texture(rt_scene *s, const unsigned char *rgb, int width, int
     t.a = (uint32_t)sc->images.size() - 1;
     return push_tex(sc, t);
 }
+void rt_rtwimage_bytes(const unsigned char *in, size_t count, unsigned char *out)
+{
+    // stbi__ldr_to_hdr: (float)(pow(byte / 255.0f, l2h_gamma = 2.2f) * l2h_scale = 1.0f)   [stb_image.h:1869]
+    // RtwImage::FloatToByte: <= 0 -> 0, >= 1 -> 255, else (unsigned char)(256.0f * v)     [R/RtwImage.h:100-105]
+    unsigned char lut[256];
+    for (int b = 0; b < 256; b++) {
+        float v = (float)(std::pow((double)((float)b / 255.0f), (double)2.2f) * (double)1.0f);
+        lut[b] = v <= 0.0f ? 0 : (1.0f <= v ? 255 : (unsigned char)(256.0f * v));
+    }
+    for (size_t k = 0; k < count; k++) out[k] = lut[in[k]];
+}
+
 rt_handle rt_noise_texture(rt_scene *s, double scale, rt_rng *rng)
 {
     if (!s || !rng) {

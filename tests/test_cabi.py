@@ -79,3 +79,15 @@ def test_render_without_gpu_fails_loudly():
         assert "no HIP device" in str(e) or "HIP error" in str(e)
     else:
         raise AssertionError("render succeeded without a GPU: a CPU fallback must not exist")
+
+
+def test_rtwimage_byte_conversion_matches_reference_formula():
+    """FloatToByte(pow(b/255, 2.2)) with the float/double mix of stb + RtwImage (R/RtwImage.h:100-105)."""
+    import numpy as np
+    src = np.arange(256, dtype=np.uint8).reshape(1, 256, 1).repeat(3, axis=2)
+    got = rt.rtwimage_bytes(src)[0, :, 0]
+    v = (np.float32(np.arange(256)) / np.float32(255.0)).astype(np.float64) ** np.float64(np.float32(2.2))
+    v = v.astype(np.float32)
+    want = np.where(v <= 0, 0, np.where(v >= 1, 255, (np.float32(256.0) * v).astype(np.uint8)))
+    assert np.array_equal(got, want.astype(np.uint8))
+    assert got[0] == 0 and got[255] == 255 and got[128] == 56 and np.all(np.diff(got.astype(int)) >= 0)

@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--coop-threshold", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--flags", type=int, default=0, help="RT_FLAG_* tuning/diagnostic bits")
     ap.add_argument("--shade-batch", type=int, default=0, help="tuning knob (0 = library default)")
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="tuning knob: cap resident workgroups per CU")
     ap.add_argument("--overdue", type=int, default=0, help="tuning knob: rays/sample budget before a pixel goes cooperative")
     args = ap.parse_args()
 
@@ -129,7 +130,7 @@ def main():
     gathered = [torch.empty_like(mine) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
     params = film.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, stream=stream,
-                         coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags, shade_batch=args.shade_batch)
+                         coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags, shade_batch=args.shade_batch, max_blocks_per_cu=args.blocks_per_cu)
 
     def step():
         film.launch(scene, params)

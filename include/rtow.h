@@ -150,7 +150,7 @@ typedef struct rt_render_params {
     int32_t coop_threshold;       /* tuning: sphere-list waves with fewer live lanes scan cooperatively (0 = default) */
     int32_t overdue_rays_per_sample; /* tuning: a pixel past this many rays/sample is finished cooperatively (0 = default 8, <0 = never) */
     int32_t shade_batch;          /* tuning: BVH kernels shade once this many lanes finished traversal (0 = default 16) */
-    int32_t reserved;
+    int32_t max_blocks_per_cu;    /* tuning: cap on resident 256-thread workgroups per CU (0 = as many as fit) */
 } rt_render_params;
 
 #define RT_FLAG_KEEP_RNG_STATE 1u  /* do not re-seed: continue from the film's saved per-pixel state (progressive) */

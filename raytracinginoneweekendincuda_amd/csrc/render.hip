@@ -867,6 +867,17 @@ DEV Vec material_texture(const DeviceScene &sc, const MaterialRec *m, uint32_t t
     return mk(0.0, 0.0, 0.0);  // unreachable: scenes with table-walking textures run the RICH instantiation
 }
 
+// pow(x, 5.0) of Schlick's approximation (R/Dielectric.h:61-67) by repeated multiplication: within 1.5 ulp of the
+// correctly rounded value, i.e. the same accuracy class as any libm's pow (the reference's is CUDA's, the oracle's
+// is glibc's, neither is bit-reproducible here).  The value only feeds the comparison `reflectance > uniform`.
+// The library pow() costs ~45 VGPRs of kernel-wide register budget -- a whole wave per SIMD of occupancy.
+DEV double pow5(double x)
+{
+    double x2 = x * x;
+    double x4 = x2 * x2;
+    return x4 * x;
+}
+
 DEV Vec random_in_unit_sphere(Xorwow &rng)  // R/Material.h:14-24
 {
     Vec p;
@@ -924,7 +935,7 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
         if (!reflect_it) {
             double r0 = (1.0 - ratio) / (1.0 + ratio);
             r0 = r0 * r0;
-            double refl = r0 + (1.0 - r0) * pow(1.0 - ct, 5.0);
+            double refl = r0 + (1.0 - r0) * pow5(1.0 - ct);
             reflect_it = refl > (double)xorwow_uniform(rng);
         }
         out.d = reflect_it ? reflect(ud, s.n) : refract(ud, s.n, ratio);
@@ -1296,6 +1307,10 @@ hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, K
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
+    // Sphere-list worlds: two resident workgroups per CU beat three although three fit -- a third wave per SIMD
+    // speeds the steady state up, but with fewer pixels per lane the frame tail grows by more (measured on C2).
+    int cap = a.max_blocks_per_cu > 0 ? a.max_blocks_per_cu : (T::WORLD == 2 ? 2 : 0);
+    if (cap > 0 && per_cu > cap) per_cu = cap;
     uint32_t resident = (uint32_t)per_cu * (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
     uint32_t blocks = (tiles + 3u) / 4u;
     if (blocks > resident) blocks = resident;

@@ -65,14 +65,27 @@ struct Surface {
 };
 
 // BVH nodes as the traversal sees them: SoA planes in LDS (or the global AoS table when they do not fit).
+// The LDS copy is addressed straight off the __shared__ symbol (see lds_node_*), never through generic pointers:
+// a pointer that may be LDS or global makes the compiler emit flat loads plus aperture arithmetic per access.
 struct NodeView {
-    const double *xlo, *xhi, *ylo, *yhi, *zlo, *zhi;  // LDS planes
-    const uint32_t *a, *b, *escape;
     const BvhNodeRec *global;
+    uint32_t n;      // number of staged nodes (plane stride)
     bool in_lds;
 };
 
 #define DEV __device__ __forceinline__
+
+extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+// BVH node planes in LDS: six double planes (xlo, xhi, ylo, yhi, zlo, zhi) then three word planes (a, b, escape)
+DEV double lds_node_f64(uint32_t n_nodes, uint32_t plane, uint32_t node)
+{
+    return reinterpret_cast<const double *>(lds_raw)[plane * n_nodes + node];
+}
+DEV uint32_t lds_node_u32(uint32_t n_nodes, uint32_t plane, uint32_t node)
+{
+    return reinterpret_cast<const uint32_t *>(lds_raw + (size_t)6 * n_nodes * sizeof(double))[plane * n_nodes + node];
+}
 
 // Scene tables are immutable for the whole launch.  Reading them through the constant address space tells
 // the compiler so: a wave-uniform row then always comes through the scalar cache into SGPRs, even though the
@@ -426,8 +439,9 @@ DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
     double xlo, xhi, ylo, yhi, zlo, zhi;
     uint32_t na, next;
     if (nv.in_lds) {
-        xlo = nv.xlo[n]; xhi = nv.xhi[n]; ylo = nv.ylo[n]; yhi = nv.yhi[n]; zlo = nv.zlo[n]; zhi = nv.zhi[n];
-        na = nv.a[n]; next = nv.escape[n];
+        xlo = lds_node_f64(nv.n, 0, n); xhi = lds_node_f64(nv.n, 1, n); ylo = lds_node_f64(nv.n, 2, n);
+        yhi = lds_node_f64(nv.n, 3, n); zlo = lds_node_f64(nv.n, 4, n); zhi = lds_node_f64(nv.n, 5, n);
+        na = lds_node_u32(nv.n, 0, n); next = lds_node_u32(nv.n, 2, n);
     } else {
         const BvhNodeRec *node = nv.global + n;
         xlo = node->xlo; xhi = node->xhi; ylo = node->ylo; yhi = node->yhi; zlo = node->zlo; zhi = node->zhi;
@@ -450,7 +464,7 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
     const uint32_t n = w.node;
     uint32_t na, nb, next;
     if (nv.in_lds) {
-        na = nv.a[n]; nb = nv.b[n]; next = nv.escape[n];
+        na = lds_node_u32(nv.n, 0, n); nb = lds_node_u32(nv.n, 1, n); next = lds_node_u32(nv.n, 2, n);
     } else {
         const BvhNodeRec *node = nv.global + n;
         na = node->a; nb = node->b; next = node->escape;
@@ -497,8 +511,14 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
 //     running closest-so-far -- the same order the reference's loop meets those spheres in.
 constexpr int kQueueCap = 12;   // entries per lane; the queue is drained whenever a lane could overflow
 constexpr int kScanUnroll = 4;
-constexpr int kBurst = 8;       // BVH worlds: at most this many node visits between two leaf phases
-constexpr int kRounds = 4;      // node/leaf phase pairs per look at the shading queue
+#ifndef RT_BURST
+#define RT_BURST 8
+#endif
+#ifndef RT_ROUNDS
+#define RT_ROUNDS 4
+#endif
+constexpr int kBurst = RT_BURST;    // BVH worlds: at most this many node visits between two leaf phases
+constexpr int kRounds = RT_ROUNDS;  // node/leaf phase pairs per look at the shading queue
 
 DEV void drain_queue(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
                      const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
@@ -1007,7 +1027,6 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a)
     a.state[5 * (size_t)a.n_pixels + local] = s.v4;
 }
 
-extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 template <int STRICT, class T>
 __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene sc, RenderArgs a)
@@ -1031,9 +1050,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 planes[4 * n + k] = node.zlo; planes[5 * n + k] = node.zhi;
                 words[0 * n + k] = node.a; words[1 * n + k] = node.b; words[2 * n + k] = node.escape;
             }
-            nv.xlo = planes; nv.xhi = planes + n; nv.ylo = planes + 2 * (size_t)n; nv.yhi = planes + 3 * (size_t)n;
-            nv.zlo = planes + 4 * (size_t)n; nv.zhi = planes + 5 * (size_t)n;
-            nv.a = words; nv.b = words + n; nv.escape = words + 2 * (size_t)n;
+            nv.n = n;
             __syncthreads();
         }
     }

@@ -511,11 +511,14 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
 //     running closest-so-far -- the same order the reference's loop meets those spheres in.
 constexpr int kQueueCap = 12;   // entries per lane; the queue is drained whenever a lane could overflow
 constexpr int kScanUnroll = 4;
+#ifndef RT_SIMPLE_BREAK
+#define RT_SIMPLE_BREAK 0
+#endif
 #ifndef RT_BURST
 #define RT_BURST 8
 #endif
 #ifndef RT_ROUNDS
-#define RT_ROUNDS 4
+#define RT_ROUNDS 8
 #endif
 constexpr int kBurst = RT_BURST;    // BVH worlds: at most this many node visits between two leaf phases
 constexpr int kRounds = RT_ROUNDS;  // node/leaf phase pairs per look at the shading queue
@@ -1183,9 +1186,13 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             for (int round = 0; round < kRounds; round++) {
                 for (int step = 0; step < kBurst; step++) {
                     const bool mover = walking && !walk.at_leaves;
+#if RT_SIMPLE_BREAK
+                    if (!__any(mover)) break;
+#else
                     const int movers = __popcll(__ballot(mover));
                     const int parked = __popcll(__ballot(walking && walk.at_leaves));
                     if (movers == 0 || movers < parked) break;  // most walkers are waiting at leaves: go test them
+#endif
                     if (mover) {
                         walk_node(nv, ray, 0.001, walk);
                         walking = walk.node != kNone;

@@ -1212,11 +1212,16 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             h = walk_best;
         }
         if ((todo >> lane) & 1ull) {
-            nrays++;
-            pix_rays++;
+            const bool no_bounces = a.max_depth <= 0;  // R/kernel.cu:71: the bounce loop never runs, RayColor returns black
+            if (!no_bounces) {
+                nrays++;
+                pix_rays++;
+            }
             if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng);
             bool path_ends;
-            if (!hit) {  // R/kernel.cu:74-79
+            if (no_bounces) {
+                path_ends = true;
+            } else if (!hit) {  // R/kernel.cu:74-79
                 accumulated = accumulated + throughput * load3c(((const RT_CONST CameraRec *)(uintptr_t)cam)->bg);
                 path_ends = true;
             } else {

@@ -180,3 +180,55 @@ def test_sub_bvh_group_equals_linear_group():
     a, _ = lin.render(W, H, SPP, variant=0)
     b, _ = few.render(W, H, SPP, variant=0)
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+# ---- edge cases ----
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (9, 17), (65, 3)])
+def test_ragged_frame_sizes(oracle, w, h):
+    """Frames that are not multiples of the 8x8 tile (the reference's W/8+1 grid with a bounds check, Q21)."""
+    for scene_id, world in ((10, 0), (11, 1), (7, 0)):
+        want = oracle.render(scene_id, world, w, h, 2)
+        got, st = rt.builtin_scene(scene_id, world, w, h).render(w, h, 2, variant=0)
+        assert st.samples == w * h * 2
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (scene_id, w, h)
+
+
+def test_depth_limits_and_zero_samples(oracle):
+    s = rt.builtin_scene(10, 0, 24, 16)
+    for depth in (1, 2, 3):
+        want = oracle.render(10, 0, 24, 16, 3, depth=depth)
+        got, _ = s.render(24, 16, 3, max_depth=depth, variant=0)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), depth
+    want0 = oracle.render(10, 0, 24, 16, 3, depth=0)   # depth 0: RayColor returns black (accumulated), R/kernel.cu:71,97
+    got0, st0 = s.render(24, 16, 3, max_depth=0, variant=0)
+    assert np.array_equal(got0, want0) and st0.rays == 0
+    film = rt.Film(24, 16)
+    st = film.render(s, 0, variant=0)                    # 0 spp: nothing launched, nothing written
+    assert st.rays == 0 and np.all(film.download() == 0)
+
+
+def test_other_seeds_match_oracle(oracle):
+    for seed in (1, 2**40 + 17):
+        want = oracle.render(0, 0, 32, 16, 2, seed=seed)
+        got, _ = rt.builtin_scene(0, 0, 32, 16, seed=seed).render(32, 16, 2, seed=seed, variant=0)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_single_leaf_bvh_with_medium_duplicated_leaf():
+    """span-1 BvhNode: left == right == the same leaf (R/BvhNode.h:63-67).  A ConstantMedium leaf is therefore hit
+    twice and draws twice; as a HittableList world it is hit once.  The two pictures must differ, and
+    the BVH one must equal the general kernel's."""
+    def build(world_kind):
+        s = rt.Scene()
+        ball = s.Sphere((0, 0, -3), 1.0, s.Dielectric(1.5))
+        fog = s.ConstantMedium(ball, 0.8, (0.9, 0.2, 0.2))
+        items = [fog]
+        s.SetWorld(s.BvhNode(items) if world_kind == 0 else s.HittableList(items))
+        s.Camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 60, W / H, 0.0, 10.0)
+        s.Commit()
+        return s
+    bvh, _ = build(0).render(W, H, 8, variant=0)
+    lst, _ = build(1).render(W, H, 8, variant=0)
+    gen, _ = build(0).render(W, H, 8, variant=0, flags=2)
+    assert np.array_equal(bvh.view(np.uint64), gen.view(np.uint64))
+    assert not np.array_equal(bvh, lst)

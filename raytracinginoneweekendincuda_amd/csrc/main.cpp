@@ -8,7 +8,99 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
 #include "../../include/rtow.h"
+
+// Multi-GPU frame: rows dealt to the N GPUs of the node in 8-row stripes (rank = stripe % N), every GPU renders its
+// stripes into a compact buffer, ONE ncclGather over xGMI brings them to GPU 0, the host de-interleaves.
+// Single process, one HIP stream and one RCCL communicator per device.
+static int render_multi_gpu(rt_scene *scene, rt_render_params base, int n_gpus, double *frame, rt_render_stats *total,
+                            double *gather_seconds)
+{
+    const int W = base.width, H = base.height, stripe = 8;
+    int rows_max = 0;
+    for (int r = 0; r < n_gpus; r++) {
+        int n = rt_stripe_rows(H, stripe, r, n_gpus, nullptr, 0);
+        if (n > rows_max) rows_max = n;
+    }
+    const size_t count = (size_t)rows_max * W * 3;  // doubles per rank
+    std::vector<rt_film *> films(n_gpus, nullptr);
+    std::vector<double *> send(n_gpus, nullptr);
+    std::vector<hipStream_t> streams(n_gpus, nullptr);
+    std::vector<ncclComm_t> comms(n_gpus);
+    std::vector<int> devs(n_gpus);
+    double *recv = nullptr;
+    auto hip_ok = [](hipError_t e, const char *what) {
+        if (e != hipSuccess) {
+            std::fprintf(stderr, "HIP error = %u at '%s'\n", (unsigned)e, what);
+            std::exit(99);
+        }
+    };
+    auto nccl_ok = [](ncclResult_t r, const char *what) {
+        if (r != ncclSuccess) {
+            std::fprintf(stderr, "RCCL error = %d (%s) at '%s'\n", (int)r, ncclGetErrorString(r), what);
+            std::exit(99);
+        }
+    };
+    for (int r = 0; r < n_gpus; r++) {
+        devs[r] = r;
+        hip_ok(hipSetDevice(r), "hipSetDevice");
+        hip_ok(hipStreamCreateWithFlags(&streams[r], hipStreamNonBlocking), "hipStreamCreate");
+        hip_ok(hipMalloc((void **)&send[r], count * sizeof(double)), "hipMalloc(send)");
+        hip_ok(hipMemsetAsync(send[r], 0, count * sizeof(double), streams[r]), "hipMemsetAsync");
+        films[r] = rt_film_create(r, W, H, stripe, r, n_gpus);
+        if (!films[r] || rt_film_bind_pixels(films[r], send[r]) != RT_OK) return 1;
+        if (rt_scene_upload(scene, r) != RT_OK) return 1;
+    }
+    hip_ok(hipSetDevice(0), "hipSetDevice(0)");
+    hip_ok(hipMalloc((void **)&recv, count * n_gpus * sizeof(double)), "hipMalloc(recv)");
+    nccl_ok(ncclCommInitAll(comms.data(), n_gpus, devs.data()), "ncclCommInitAll");
+
+    for (int r = 0; r < n_gpus; r++) {  // all GPUs render concurrently
+        rt_render_params p = base;
+        p.device = r;
+        p.rank = r;
+        p.world_size = n_gpus;
+        p.stripe_rows = stripe;
+        p.stream = streams[r];
+        if (rt_render_launch(scene, films[r], &p) != RT_OK) return 1;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    nccl_ok(ncclGroupStart(), "ncclGroupStart");
+    for (int r = 0; r < n_gpus; r++)
+        nccl_ok(ncclGather(send[r], r == 0 ? recv : nullptr, count, ncclDouble, 0, comms[r], streams[r]), "ncclGather");
+    nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+    std::memset(total, 0, sizeof *total);
+    for (int r = 0; r < n_gpus; r++) {
+        rt_render_stats st{};
+        if (rt_render_finish(scene, films[r], &st) != RT_OK) return 1;
+        hip_ok(hipSetDevice(r), "hipSetDevice");
+        hip_ok(hipStreamSynchronize(streams[r]), "hipStreamSynchronize");
+        total->samples += st.samples;
+        total->rays += st.rays;
+        if (st.seconds_render + st.seconds_seed > total->seconds_render) total->seconds_render = st.seconds_render + st.seconds_seed;
+        total->kernel_vgprs = st.kernel_vgprs;
+        total->lds_bytes = st.lds_bytes;
+        total->kernel_kind = st.kernel_kind;
+    }
+    *gather_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> gathered(count * n_gpus);
+    hip_ok(hipSetDevice(0), "hipSetDevice(0)");
+    hip_ok(hipMemcpy(gathered.data(), recv, gathered.size() * sizeof(double), hipMemcpyDeviceToHost), "hipMemcpy(D2H)");
+    int rc = rt_deinterleave(gathered.data(), W, H, stripe, n_gpus, count, frame);
+    for (int r = 0; r < n_gpus; r++) {
+        hipSetDevice(r);
+        ncclCommDestroy(comms[r]);
+        rt_film_destroy(films[r]);
+        hipFree(send[r]);
+        hipStreamDestroy(streams[r]);
+    }
+    hipSetDevice(0);
+    hipFree(recv);
+    return rc;
+}
 
 static int die(const char *what)
 {
@@ -18,7 +110,7 @@ static int die(const char *what)
 
 int main(int argc, char **argv)
 {
-    int width = 1440, height = 720, scene_id = 9, spp = -1, depth = 50, world_kind = 0, variant = 1, device = 0;
+    int width = 1440, height = 720, scene_id = 9, spp = -1, depth = 50, world_kind = 0, variant = 1, device = 0, gpus = 0;
     unsigned long long seed = 1984;
     std::string out = "output.ppm";
     for (int k = 1; k < argc; k++) {
@@ -36,11 +128,12 @@ int main(int argc, char **argv)
         else if (const char *v = val("--world")) world_kind = std::strcmp(v, "list") == 0 ? 1 : 0;
         else if (const char *v = val("--variant")) variant = std::strcmp(v, "strict") == 0 ? 0 : 1;
         else if (const char *v = val("--device")) device = std::atoi(v);
+        else if (const char *v = val("--gpus")) gpus = std::atoi(v);  // >= 1: stripe the frame over that many GPUs + one RCCL gather
         else if (const char *v = val("--output")) out = v;
         else {
             std::fprintf(stderr,
                          "usage: rtow [--scene 0..11] [--width W] [--height H] [--spp N] [--depth D] [--seed S]\n"
-                         "            [--world bvh|list] [--variant strict|fast] [--device N] [--output file.ppm]\n");
+                         "            [--world bvh|list] [--variant strict|fast] [--device N] [--gpus N] [--output file.ppm]\n");
             return 2;
         }
     }
@@ -64,9 +157,15 @@ int main(int argc, char **argv)
     std::vector<double> frame((size_t)width * height * 3);
     rt_render_stats st{};
     auto t0 = std::chrono::steady_clock::now();
-    if (rt_render(scene, &p, frame.data(), &st) != RT_OK) return die("render");
+    double gather_s = 0.0;
+    if (gpus >= 1) {
+        if (render_multi_gpu(scene, p, gpus, frame.data(), &st, &gather_s) != 0) return die("render (multi-GPU)");
+    } else if (rt_render(scene, &p, frame.data(), &st) != RT_OK) {
+        return die("render");
+    }
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     double kern = st.seconds_seed + st.seconds_render;
+    if (gpus >= 1) std::fprintf(stderr, "%d GPU(s): slowest rank %.4f s of kernels; launch-to-gathered %.4f s\n", gpus, kern, gather_s);
     std::fprintf(stderr, "took %g seconds.\n", kern);
     std::fprintf(stderr, "%.1f Msamples/s, %.1f Mray/s (kernels); %.3f s wall incl. upload/download\n",
                  st.samples / kern * 1e-6, st.rays / kern * 1e-6, wall);

@@ -232,3 +232,25 @@ def test_single_leaf_bvh_with_medium_duplicated_leaf():
     gen, _ = build(0).render(W, H, 8, variant=0, flags=2)
     assert np.array_equal(bvh.view(np.uint64), gen.view(np.uint64))
     assert not np.array_equal(bvh, lst)
+
+
+def test_rtow_executable_and_rccl_gather_path(tmp_path):
+    """The thin C++ host executable (the reference's main()): direct path, and the striped multi-GPU path with its
+    RCCL gather (exercised here with a communicator of one), both byte-identical to the API's PPM."""
+    import hashlib
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.library_path()), "rtow")
+    args = ["--scene", "10", "--width", "48", "--height", "32", "--spp", "3", "--variant", "strict"]
+    a, b, c = tmp_path / "a.ppm", tmp_path / "b.ppm", tmp_path / "c.ppm"
+    r = subprocess.run([exe, *args, "--output", str(a)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Rendering a 48x32 image with 3 samples per pixel in 8x8 blocks." in r.stderr and "Done. Saved to" in r.stderr
+    r = subprocess.run([exe, *args, "--gpus", "1", "--output", str(b)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    frame, _ = rt.builtin_scene(10, 0, 48, 32).render(48, 32, 3, variant=0)
+    rt.write_ppm(c, frame)
+    digests = {hashlib.md5(p.read_bytes()).hexdigest() for p in (a, b, c)}
+    assert len(digests) == 1
+    bad = subprocess.run([exe, "--scene", "99"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 99  # the reference's checkCudaErrors exit code (R/kernel.cu:29-40)

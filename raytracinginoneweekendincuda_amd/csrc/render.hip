@@ -509,7 +509,7 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
 //     (disc > 0 and not "outside and behind") appends k to its own queue in LDS;
 //  2. each lane walks its own queue in ascending k and does the sqrt / divide root selection against its
 //     running closest-so-far -- the same order the reference's loop meets those spheres in.
-constexpr int kQueueCap = 12;   // entries per lane; the queue is drained whenever a lane could overflow
+constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenever a lane could overflow
 constexpr int kScanUnroll = 4;
 #ifndef RT_SIMPLE_BREAK
 #define RT_SIMPLE_BREAK 0
@@ -577,30 +577,47 @@ DEV void scan_one(const SphereGeom &g, uint32_t k, const Ray &r, double a, uint1
     }
 }
 
+// A no-op that *uses* four scalar rows: it makes the compiler place the wait for those rows here, i.e. before
+// the next batch of scalar loads is issued.  (Scalar loads return out of order, so every wait is lgkmcnt(0); a wait
+// placed after the next loads were issued would also wait for them and undo the prefetch.)
+DEV void rows_arrived(const SphereGeom &g0, const SphereGeom &g1, const SphereGeom &g2, const SphereGeom &g3)
+{
+    asm volatile("" ::"s"(g0.cx), "s"(g0.cy), "s"(g0.cz), "s"(g0.r2), "s"(g1.cx), "s"(g1.cy), "s"(g1.cz), "s"(g1.r2));
+    asm volatile("" ::"s"(g2.cx), "s"(g2.cy), "s"(g2.cz), "s"(g2.r2), "s"(g3.cx), "s"(g3.cy), "s"(g3.cz), "s"(g3.r2));
+}
+
 // Pixel-parallel scan: every live lane traces its own ray; sphere rows are wave-uniform (scalar path).
 DEV bool scan_uniform(const DeviceScene &sc, uint16_t *queue, uint32_t lane, const Ray &r, double tmin, double tmax, HitInfo &best)
 {
     const SphereGeom *__restrict__ spheres = sc.spheres;
     const uint32_t n = sc.n_spheres;
-    const uint32_t n4 = n & ~3u;
+    const uint32_t n8 = n & ~7u;
     const double a = dot(r.d, r.d);
     double closest = tmax;
     uint32_t best_k = kNone, count = 0;
-    // groups of four rows, the next group's scalar loads in flight while this group is evaluated
-    SphereGeom g0{}, g1{}, g2{}, g3{};
-    if (n4) {
-        g0 = load_sphere_row(spheres, 0); g1 = load_sphere_row(spheres, 1);
-        g2 = load_sphere_row(spheres, 2); g3 = load_sphere_row(spheres, 3);
+    // Eight rows per trip in two register sets (A, B): while one set is evaluated the other one's scalar loads are
+    // in flight, and no set is ever copied into another.
+    SphereGeom a0{}, a1{}, a2{}, a3{};
+    if (n8) {
+        a0 = load_sphere_row(spheres, 0); a1 = load_sphere_row(spheres, 1);
+        a2 = load_sphere_row(spheres, 2); a3 = load_sphere_row(spheres, 3);
     }
-    for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
-        const uint32_t kn = (k0 + 4 < n4) ? k0 + 4 : k0;  // last group re-reads itself (stays in bounds)
-        const SphereGeom h0 = load_sphere_row(spheres, kn), h1 = load_sphere_row(spheres, kn + 1);
-        const SphereGeom h2 = load_sphere_row(spheres, kn + 2), h3 = load_sphere_row(spheres, kn + 3);
-        scan_four(g0, g1, g2, g3, k0, r, a, queue, lane, count);
-        g0 = h0; g1 = h1; g2 = h2; g3 = h3;
-        if (__any(count > (uint32_t)(kQueueCap - kScanUnroll))) drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    for (uint32_t k0 = 0; k0 < n8; k0 += 8) {
+        rows_arrived(a0, a1, a2, a3);
+        const SphereGeom b0 = load_sphere_row(spheres, k0 + 4), b1 = load_sphere_row(spheres, k0 + 5);
+        const SphereGeom b2 = load_sphere_row(spheres, k0 + 6), b3 = load_sphere_row(spheres, k0 + 7);
+        scan_four(a0, a1, a2, a3, k0, r, a, queue, lane, count);
+        const uint32_t kn = (k0 + 8 < n8) ? k0 + 8 : k0;  // last trip re-reads its own rows (stays in bounds)
+        rows_arrived(b0, b1, b2, b3);
+        a0 = load_sphere_row(spheres, kn); a1 = load_sphere_row(spheres, kn + 1);
+        a2 = load_sphere_row(spheres, kn + 2); a3 = load_sphere_row(spheres, kn + 3);
+        scan_four(b0, b1, b2, b3, k0 + 4, r, a, queue, lane, count);
+        if (__any(count > (uint32_t)(kQueueCap - 8))) drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
     }
-    for (uint32_t k = n4; k < n; k++) scan_one(load_sphere_row(spheres, k), k, r, a, queue, lane, count);
+    for (uint32_t k = n8; k < n; k++) {
+        scan_one(load_sphere_row(spheres, k), k, r, a, queue, lane, count);
+        if (__any(count >= (uint32_t)kQueueCap)) drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    }
     drain_queue(spheres, queue, lane, count, r, a, tmin, closest, best_k);
     if (best_k == kNone) return false;
     best.t = closest;

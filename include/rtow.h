@@ -148,7 +148,7 @@ typedef struct rt_render_params {
     int32_t flags;                /* RT_FLAG_* */
     void *stream;                 /* hipStream_t to launch on (NULL = the film's own stream) */
     int32_t coop_threshold;       /* tuning: sphere-list waves with fewer live lanes scan cooperatively (0 = default) */
-    int32_t overdue_rays_per_sample; /* tuning: a pixel past this many rays/sample is finished cooperatively (0 = default 8, <0 = never) */
+    int32_t overdue_rays_per_sample; /* tuning: a pixel past this many rays/sample advances in extra cooperative passes (0 or <0 = never, the default) */
     int32_t shade_batch;          /* tuning: BVH kernels shade once this many lanes finished traversal (0 = default 16) */
     int32_t max_blocks_per_cu;    /* tuning: cap on resident 256-thread workgroups per CU (0 = as many as fit) */
 } rt_render_params;

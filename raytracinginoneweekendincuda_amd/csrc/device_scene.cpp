@@ -3,6 +3,7 @@
 // timing.  Replaces the host driver section R/kernel.cu:675-691.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -274,10 +275,16 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.num_cus = f.num_cus;
     ra.shade_batch = p->shade_batch > 0 ? p->shade_batch : 16;
     ra.max_blocks_per_cu = p->max_blocks_per_cu;
+    ra.boost_rounds = 8;
+    if (const char *e = std::getenv("RTOW_BOOST")) ra.boost_rounds = std::atoi(e);  // experiments only
+    ra.grid_blocks = 0;
+    if (const char *e = std::getenv("RTOW_GRID_BLOCKS")) ra.grid_blocks = std::atoi(e);  // experiments only
+    if (ra.grid_blocks > 0) ra.max_blocks_per_cu = 8;
     ra.overdue_priority = (p->flags & RT_FLAG_OVERDUE_PRIORITY) ? 1 : 0;
     {
-        // default budget: 8 rays per sample (about the 98th percentile of the Book-1 scenes)
-        double per_sample = p->overdue_rays_per_sample > 0 ? (double)p->overdue_rays_per_sample : 8.0;
+        // Off by default: on the Book-1 scenes a cooperative ray costs ~10x a pixel-parallel one, and every budget
+        // tried (3..16 rays/sample, 2..32 boost rounds) lost more in throughput than it won back in frame tail.
+        double per_sample = p->overdue_rays_per_sample > 0 ? (double)p->overdue_rays_per_sample : 1.0e9;
         double budget = per_sample * (double)p->samples_per_pixel;
         ra.ray_budget = budget >= 4.0e9 ? 0xFFFFFFFFu : (uint32_t)budget;
         if (p->overdue_rays_per_sample < 0) ra.ray_budget = 0xFFFFFFFFu;  // negative: never

@@ -1112,6 +1112,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     uint32_t nrays = 0;
 
     uint32_t pix_rays = 0;  // rays this lane's current pixel has traced so far
+    int boost_left = 0;     // extra overdue-only passes still allowed before the next pixel-parallel pass
     // BVH worlds: per-lane resumable traversal (see Walk) and the hit it has found so far
     Walk walk{};
     HitInfo walk_best;
@@ -1122,9 +1123,11 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
 
     for (;;) {
         // A pixel that has used up its ray budget is "overdue": its samples cannot be spread over lanes (one
-        // sequential RNG stream per pixel), so instead the whole wave works on each of its rays (cooperative
-        // scan) until it is finished -- that bounds the frame's critical path by the budget, not by the pixel.
+        // sequential RNG stream per pixel), and at one ray per pixel-parallel pass it would finish long after the
+        // rest of the frame.  So after every pixel-parallel pass the wave inserts up to `boost_rounds` extra passes
+        // in which only the overdue lanes advance, each of their rays scanned cooperatively by all 64 lanes.
         unsigned long long overdue = 0;
+        bool boost = false;
         if constexpr (T::WORLD == 2) {
             overdue = __ballot(active && pix_rays >= a.ray_budget);
             if (a.overdue_priority) {  // diagnostic alternative: keep the pixel-parallel scan but raise this wave's issue priority
@@ -1132,9 +1135,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 else __builtin_amdgcn_s_setprio(0);
                 overdue = 0;
             }
+            boost = overdue != 0 && boost_left > 0;
+            if (boost) boost_left--;
+            else boost_left = a.boost_rounds;
         }
 
-        if (!exhausted && !overdue) {
+        if (!exhausted && !boost) {
             const unsigned long long need = __ballot(!active);
             if (need) {
                 const uint32_t cnt = (uint32_t)__popcll(need);
@@ -1187,8 +1193,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         h.obj = kNone;
         bool hit = false;
         if constexpr (T::WORLD == 2) {
-            if (overdue) todo = overdue & (~overdue + 1ull);  // one overdue pixel at a time, lowest lane first
-            if (!overdue && __popcll(live) >= a.coop_threshold) {
+            if (boost) todo = overdue;
+            if (!boost && __popcll(live) >= a.coop_threshold) {
                 if (active) hit = scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h);
             } else {
                 scan_cooperative(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
@@ -1360,6 +1366,7 @@ hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, K
     uint32_t resident = (uint32_t)per_cu * (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
     uint32_t blocks = (tiles + 3u) / 4u;
     if (blocks > resident) blocks = resident;
+    if (a.grid_blocks > 0 && blocks > (uint32_t)a.grid_blocks) blocks = (uint32_t)a.grid_blocks;  // tuning experiments
     dim3 grid(blocks), block(256);
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, a);
     return hipGetLastError();

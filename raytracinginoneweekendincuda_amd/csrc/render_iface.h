@@ -32,6 +32,8 @@ struct RenderArgs {
     int32_t num_cus;
     int32_t lds_spheres;    // set by the launcher: sphere planes staged in LDS for the cooperative scan
     int32_t overdue_priority;
+    int32_t boost_rounds;   // overdue-only cooperative passes inserted after each pixel-parallel pass
+    int32_t grid_blocks;        // tuning: hard cap on the persistent grid (0 = none)
     int32_t max_blocks_per_cu;  // tuning: cap on resident workgroups per CU (0 = whatever fits)
     int32_t shade_batch;    // BVH kernels: shade once this many lanes have finished their walk
     uint32_t ray_budget;    // sphere-list kernel: a pixel past this many rays is finished cooperatively

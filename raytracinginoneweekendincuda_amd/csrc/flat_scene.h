@@ -116,6 +116,7 @@ enum : uint32_t {
     SCENE_HAS_MEDIA = 1u,
     SCENE_LIST_ALL_SPHERES = 2u,  // WORLD_LIST whose leaves are spheres 0..n-1 in order (config C2 fast path)
     SCENE_RICH_TEXTURES = 4u,     // some texture is an ImageTexture or NoiseTexture
+    SCENE_MS_UNIT_TIME = 8u,      // every moving-sphere row has time0 = 0, time1 - time0 = 1: frac == ray time
 };
 
 } // namespace rtow

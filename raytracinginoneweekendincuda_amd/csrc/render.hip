@@ -182,9 +182,10 @@ DEV bool quad_test(const QuadGeom &q, const Ray &r, double tmin, double tmax, do
     return true;
 }
 
-DEV Vec msphere_center(const MSphereGeom &g, double tm)  // R/MovingSphere.h:51-52
+// unit_time: every row has time0 = 0 and time1 - time0 = 1, so (tm - 0) / 1 == tm exactly and the divide is skipped
+DEV Vec msphere_center(const MSphereGeom &g, double tm, bool unit_time = false)  // R/MovingSphere.h:51-52
 {
-    double frac = (tm - g.t0) / g.dt;
+    double frac = unit_time ? tm : (tm - g.t0) / g.dt;
     return mk(g.c0x, g.c0y, g.c0z) + frac * mk(g.dcx, g.dcy, g.dcz);
 }
 
@@ -198,7 +199,7 @@ DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
     }
     case REF_MSPHERE: {
         MSphereGeom g = sc.mspheres[idx];
-        return sphere_test(r.o - msphere_center(g, r.tm), r.d, a, g.r2, tmin, tmax, t);
+        return sphere_test(r.o - msphere_center(g, r.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0), r.d, a, g.r2, tmin, tmax, t);
     }
     default: {
         return quad_test(sc.quads[idx], r, tmin, tmax, t);
@@ -510,7 +511,6 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
 //  2. each lane walks its own queue in ascending k and does the sqrt / divide root selection against its
 //     running closest-so-far -- the same order the reference's loop meets those spheres in.
 constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenever a lane could overflow
-constexpr int kScanUnroll = 4;
 #ifndef RT_SIMPLE_BREAK
 #define RT_SIMPLE_BREAK 0
 #endif
@@ -797,7 +797,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
             c = mk(g.cx, g.cy, g.cz);
             aux = sc.sphere_aux[idx];
         } else {
-            c = msphere_center(sc.mspheres[idx], lr.tm);
+            c = msphere_center(sc.mspheres[idx], lr.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0);
             aux = sc.msphere_aux[idx];
         }
         Vec on = aux.inv_r * (s.p - c);

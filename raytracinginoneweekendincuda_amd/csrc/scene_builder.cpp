@@ -252,8 +252,18 @@ struct Flattener {
     };
     std::vector<PendingSubBvh> pending;
 
-    uint32_t add_primitive(const HostHittable &h)
+    // When a BVH world mixes Sphere and MovingSphere leaves, static spheres are stored as moving-sphere rows with a
+    // zero displacement (centre(t) = c0 + frac * 0 = c0 exactly), so that a wave's leaf tests run one code path
+    // instead of two.  Not done if a centre component is -0.0 (c0 + 0.0 would flip it to +0.0).
+    bool unify_spheres = false;
+
+    uint32_t add_primitive(const HostHittable &h, bool world_leaf = false)
     {
+        if (h.kind == HKind::Sphere && unify_spheres && world_leaf) {
+            f.mspheres.push_back({h.c0.x, h.c0.y, h.c0.z, 0.0, 0.0, 0.0, 0.0, 1.0, h.radius * h.radius});
+            f.msphere_aux.push_back({1 / h.radius, h.material - 1, 0});
+            return make_ref(REF_MSPHERE, (uint32_t)f.mspheres.size() - 1);
+        }
         if (h.kind == HKind::Sphere) {
             f.spheres.push_back({h.c0.x, h.c0.y, h.c0.z, h.radius * h.radius});
             f.sphere_aux.push_back({1 / h.radius, h.material - 1, 0});
@@ -297,7 +307,7 @@ struct Flattener {
     uint32_t lower_leaf(uint32_t handle)
     {
         const HostHittable *h = &s.hittables[handle - 1];
-        if (is_primitive(h->kind)) return add_primitive(*h);
+        if (is_primitive(h->kind)) return add_primitive(*h, true);
 
         ObjectRec obj{};
         obj.medium = kNone;
@@ -505,6 +515,20 @@ int flatten_scene(SceneImpl &s)
         if (k == HKind::Bvh && world.kind != HKind::Bvh)
             return fail(RT_ERR_UNSUPPORTED, "unsupported nesting: BvhNode inside a list world");
     }
+    if (f.world_kind == WORLD_BVH) {
+        bool any_static = false, any_moving = false, negative_zero = false;
+        for (uint32_t h : leaves) {
+            const HostHittable &hh = s.hittables[h - 1];
+            any_moving |= hh.kind == HKind::MovingSphere;
+            if (hh.kind == HKind::Sphere) {
+                any_static = true;
+                negative_zero |= std::signbit(hh.c0.x) && hh.c0.x == 0.0;
+                negative_zero |= std::signbit(hh.c0.y) && hh.c0.y == 0.0;
+                negative_zero |= std::signbit(hh.c0.z) && hh.c0.z == 0.0;
+            }
+        }
+        fl.unify_spheres = any_static && any_moving && !negative_zero;
+    }
     std::vector<uint32_t> ref_of_handle(s.hittables.size() + 1, kNone);
     for (uint32_t h : leaves) {
         uint32_t ref = fl.lower_leaf(h);
@@ -512,6 +536,8 @@ int flatten_scene(SceneImpl &s)
         ref_of_handle[h] = ref;
         f.world_items.push_back(ref);
         f.leaf_boxes.push_back(s.hittables[h - 1].box);
+        const HKind hk = s.hittables[h - 1].kind;
+        f.leaf_kinds.push_back(hk == HKind::Sphere ? 0 : (hk == HKind::MovingSphere ? 1 : (hk == HKind::Quad ? 2 : 3)));
     }
     if (f.world_kind == WORLD_BVH) {
         if (world.tree.empty()) return fail(RT_ERR_INVALID, "BvhNode world has no nodes");
@@ -523,6 +549,11 @@ int flatten_scene(SceneImpl &s)
         if (all_spheres && f.spheres.size() == f.world_items.size()) f.flags |= SCENE_LIST_ALL_SPHERES;
     }
     fl.emit_pending();
+    {
+        bool unit_time = !f.mspheres.empty();
+        for (const MSphereGeom &m : f.mspheres) unit_time &= (m.t0 == 0.0 && m.dt == 1.0);
+        if (unit_time) f.flags |= SCENE_MS_UNIT_TIME;
+    }
     s.committed = true;
     return RT_OK;
 }
@@ -989,7 +1020,7 @@ int rt_scene_dump_leaves(rt_scene *s, int max_leaves, int *kind_out, double *box
     const FlatScene &f = S(s)->flat;
     int n = (int)f.world_items.size();
     for (int k = 0; k < n && k < max_leaves; k++) {
-        if (kind_out) kind_out[k] = (int)(f.world_items[k] >> kRefShift);
+        if (kind_out) kind_out[k] = f.leaf_kinds[k];
         if (box_out)
             for (int a = 0; a < 3; a++) {
                 box_out[6 * k + 2 * a] = f.leaf_boxes[k].lo[a];

@@ -70,6 +70,7 @@ struct FlatScene {
     std::vector<BvhNodeRec> nodes;
     std::vector<uint32_t> world_items;   // leaf refs in final order (both world kinds)
     std::vector<Box> leaf_boxes;         // introspection
+    std::vector<int> leaf_kinds;         // introspection: the leaf's kind as constructed (0 sphere, 1 moving sphere, 2 quad, 3 composite)
     std::vector<MaterialRec> materials;
     std::vector<TextureRec> textures;
     std::vector<ImageRec> images;

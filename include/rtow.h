@@ -155,6 +155,8 @@ typedef struct rt_render_params {
 
 #define RT_FLAG_KEEP_RNG_STATE 1u  /* do not re-seed: continue from the film's saved per-pixel state (progressive) */
 #define RT_FLAG_OVERDUE_PRIORITY 4u /* tuning/diagnostics: overdue pixels raise their wave's priority instead of going cooperative */
+#define RT_FLAG_ACCUMULATE 8u      /* progressive: with KEEP_RNG_STATE, add this launch's samples to the film's running sums;
+                                      the pixels then hold sqrt(sum / all samples so far), bit-identical to one launch of that many spp */
 #define RT_FLAG_FORCE_GENERAL 2u   /* tests: run the general kernel even where a specialised instantiation applies */
 
 typedef struct rt_render_stats {
@@ -198,6 +200,11 @@ RTOW_API int rt_deinterleave(const double *gathered, int width, int height, int 
 
 /* Convenience: create film, upload, render 1 GPU, download.  frame = W*H*3 doubles. */
 RTOW_API int rt_render(rt_scene *s, const rt_render_params *params, double *frame, rt_render_stats *stats);
+
+/* Extra outputs: binary PPM (P6, same quantisation as the P3 writer) and PFM (little-endian float32, the
+ * gamma-corrected values unclamped, bottom row first as PFM prescribes). */
+RTOW_API int rt_write_ppm_binary(const char *path, const double *frame, int width, int height);
+RTOW_API int rt_write_pfm(const char *path, const double *frame, int width, int height);
 
 /* PPM writer, byte-for-byte the reference's (R/kernel.cu:696-721): P3, rows from j=H-1 down, clamp [0,0.999], int(256*c). */
 RTOW_API int rt_write_ppm(const char *path, const double *frame, int width, int height);

@@ -15,6 +15,8 @@ from .api import (  # noqa: F401
     stripe_rows,
     deinterleave,
     write_ppm,
+    write_ppm_binary,
+    write_pfm,
     rtwimage_bytes,
     load_image,
     library_path,
@@ -23,5 +25,5 @@ from .api import (  # noqa: F401
 
 __all__ = [
     "RtowError", "Rng", "Scene", "Film", "RenderParams", "RenderStats", "builtin_scene",
-    "stripe_rows", "deinterleave", "write_ppm", "rtwimage_bytes", "load_image", "library_path", "lib",
+    "stripe_rows", "deinterleave", "write_ppm", "write_ppm_binary", "write_pfm", "rtwimage_bytes", "load_image", "library_path", "lib",
 ]

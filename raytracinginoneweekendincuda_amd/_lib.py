@@ -94,6 +94,8 @@ SIGNATURES = {
     "rt_deinterleave": (I, [D3, I, I, I, I, C.c_size_t, D3]),
     "rt_render": (I, [P, C.POINTER(RenderParams), D3, C.POINTER(RenderStats)]),
     "rt_write_ppm": (I, [C.c_char_p, D3, I, I]),
+    "rt_write_ppm_binary": (I, [C.c_char_p, D3, I, I]),
+    "rt_write_pfm": (I, [C.c_char_p, D3, I, I]),
 }
 
 _lib = None

@@ -314,6 +314,16 @@ def deinterleave(gathered, width, height, stripe, world_size):
     return frame
 
 
+def write_ppm_binary(path, frame):
+    f = np.ascontiguousarray(frame, dtype=np.float64)
+    _check(lib().rt_write_ppm_binary(str(path).encode(), f.ctypes.data_as(_lib.D3), f.shape[1], f.shape[0]))
+
+
+def write_pfm(path, frame):
+    f = np.ascontiguousarray(frame, dtype=np.float64)
+    _check(lib().rt_write_pfm(str(path).encode(), f.ctypes.data_as(_lib.D3), f.shape[1], f.shape[0]))
+
+
 def write_ppm(path, frame):
     f = np.ascontiguousarray(frame, dtype=np.float64)
     _check(lib().rt_write_ppm(str(path).encode(), f.ctypes.data_as(_lib.D3), f.shape[1], f.shape[0]))

@@ -96,6 +96,8 @@ struct FilmImpl {
     uint32_t n_pixels = 0;
     double *pixels = nullptr;      // where the kernel writes (own_pixels or a bound external buffer)
     double *own_pixels = nullptr;
+    double *accum = nullptr;       // progressive rendering: unnormalised colour sums (allocated on first use)
+    int accum_spp = 0;
     uint32_t *state = nullptr;
     unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor
     int num_cus = 256;
@@ -217,6 +219,7 @@ void rt_film_destroy(rt_film *film)
     FilmImpl *f = F(film);
     hipSetDevice(f->device);
     if (f->own_pixels) hipFree(f->own_pixels);
+    if (f->accum) hipFree(f->accum);
     if (f->state) hipFree(f->state);
     if (f->ray_counter) hipFree(f->ray_counter);
     for (int k = 0; k < 3; k++)
@@ -268,6 +271,17 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     HIP_TRY(hipEventRecord(f.ev[1], stream));
     RenderArgs ra{};
     ra.pixels = f.pixels;
+    if (p->flags & RT_FLAG_ACCUMULATE) {
+        // progressive frame: this launch's samples are added to the film's running sums (needs the saved RNG streams)
+        if (!f.accum) {
+            HIP_TRY(hipMalloc((void **)&f.accum, (size_t)(f.n_pixels ? f.n_pixels : 1) * 3 * sizeof(double)));
+            f.accum_spp = 0;
+        }
+        if (!keep) f.accum_spp = 0;  // re-seeded: start a new frame
+        ra.accum = f.accum;
+        ra.spp_before = f.accum_spp;
+        if (p->samples_per_pixel > 0) f.accum_spp += p->samples_per_pixel;
+    }
     ra.state = f.state;
     ra.ray_counter = f.ray_counter;
     ra.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 1);

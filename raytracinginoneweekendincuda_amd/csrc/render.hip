@@ -1164,6 +1164,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         rng.v3 = a.state[4 * (size_t)a.n_pixels + local];
                         rng.v4 = a.state[5 * (size_t)a.n_pixels + local];
                         col = mk(0.0, 0.0, 0.0);
+                        if (a.accum && a.spp_before > 0)  // progressive: continue the running sum in the same order
+                            col = mk(a.accum[local * 3 + 0], a.accum[local * 3 + 1], a.accum[local * 3 + 2]);
                         throughput = mk(1.0, 1.0, 1.0);
                         accumulated = mk(0.0, 0.0, 0.0);
                         sample = 0;
@@ -1267,7 +1269,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                     a.state[3 * (size_t)a.n_pixels + local] = rng.v2;
                     a.state[4 * (size_t)a.n_pixels + local] = rng.v3;
                     a.state[5 * (size_t)a.n_pixels + local] = rng.v4;
-                    col = over(col, (double)a.spp);
+                    if (a.accum) {
+                        a.accum[local * 3 + 0] = col.x;
+                        a.accum[local * 3 + 1] = col.y;
+                        a.accum[local * 3 + 2] = col.z;
+                    }
+                    col = over(col, (double)(a.spp_before + a.spp));
                     a.pixels[local * 3 + 0] = sqrt(col.x);
                     a.pixels[local * 3 + 1] = sqrt(col.y);
                     a.pixels[local * 3 + 2] = sqrt(col.z);

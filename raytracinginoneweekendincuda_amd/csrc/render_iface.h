@@ -19,6 +19,8 @@ struct SeedArgs {
 
 struct RenderArgs {
     double *pixels;              // rows_owned x width x 3
+    double *accum;               // progressive rendering: running (unnormalised) colour sums, or nullptr
+    int32_t spp_before;          // samples already in accum
     uint32_t *state;
     unsigned long long *ray_counter;
     uint32_t *cursor;            // pixel-queue cursor, zeroed before every launch

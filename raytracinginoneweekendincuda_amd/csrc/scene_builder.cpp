@@ -1087,6 +1087,40 @@ int rt_deinterleave(const double *gathered, int width, int height, int stripe_ro
     return RT_OK;
 }
 
+int rt_write_ppm_binary(const char *path, const double *frame, int width, int height)
+{
+    if (!path || !frame || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_write_ppm_binary: bad arguments");
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(RT_ERR_INVALID, std::string("rt_write_ppm_binary: cannot open ") + path);
+    std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
+    std::vector<unsigned char> row((size_t)width * 3);
+    for (int j = height - 1; j >= 0; j--) {  // same clamp and int(256 * c) as R/kernel.cu:710-718
+        for (int i = 0; i < width * 3; i++) {
+            double c = frame[(size_t)j * width * 3 + i];
+            double x = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);
+            row[i] = (unsigned char)(int)(256.0 * x);
+        }
+        std::fwrite(row.data(), 1, row.size(), fp);
+    }
+    std::fclose(fp);
+    return RT_OK;
+}
+
+int rt_write_pfm(const char *path, const double *frame, int width, int height)
+{
+    if (!path || !frame || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_write_pfm: bad arguments");
+    FILE *fp = std::fopen(path, "wb");
+    if (!fp) return fail(RT_ERR_INVALID, std::string("rt_write_pfm: cannot open ") + path);
+    std::fprintf(fp, "PF\n%d %d\n-1.0\n", width, height);
+    std::vector<float> row((size_t)width * 3);
+    for (int j = 0; j < height; j++) {  // PFM stores the bottom row first: the frame's own order (j = 0 bottom)
+        for (int i = 0; i < width * 3; i++) row[i] = (float)frame[(size_t)j * width * 3 + i];
+        std::fwrite(row.data(), sizeof(float), row.size(), fp);
+    }
+    std::fclose(fp);
+    return RT_OK;
+}
+
 int rt_write_ppm(const char *path, const double *frame, int width, int height)
 {
     if (!path || !frame || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_write_ppm: bad arguments");

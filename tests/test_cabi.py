@@ -91,3 +91,21 @@ def test_rtwimage_byte_conversion_matches_reference_formula():
     want = np.where(v <= 0, 0, np.where(v >= 1, 255, (np.float32(256.0) * v).astype(np.uint8)))
     assert np.array_equal(got, want.astype(np.uint8))
     assert got[0] == 0 and got[255] == 255 and got[128] == 56 and np.all(np.diff(got.astype(int)) >= 0)
+
+
+def test_binary_ppm_and_pfm_writers(tmp_path):
+    import numpy as np
+    rng = np.random.default_rng(3)
+    frame = rng.uniform(-0.1, 1.2, size=(5, 7, 3))
+    p3, p6, pf = tmp_path / "a.ppm", tmp_path / "b.ppm", tmp_path / "c.pfm"
+    rt.write_ppm(p3, frame); rt.write_ppm_binary(p6, frame); rt.write_pfm(pf, frame)
+    text = p3.read_text().split()
+    assert text[:4] == ["P3", "7", "5", "255"]
+    vals = np.array(text[4:], dtype=np.int64)
+    raw = p6.read_bytes()
+    assert raw.startswith(b"P6\n7 5\n255\n") and np.array_equal(np.frombuffer(raw[len(b"P6\n7 5\n255\n"):], dtype=np.uint8), vals)
+    want = (256.0 * np.clip(frame[::-1], 0.0, 0.999)).astype(np.int64).ravel()   # top row first, clamp, truncate
+    assert np.array_equal(vals, want)
+    body = pf.read_bytes()
+    assert body.startswith(b"PF\n7 5\n-1.0\n")
+    assert np.array_equal(np.frombuffer(body[len(b"PF\n7 5\n-1.0\n"):], dtype="<f4"), frame.astype(np.float32).ravel())

@@ -100,6 +100,19 @@ def test_progressive_state_is_saved_and_resumed():
     assert np.allclose(np.sqrt(lin), four, atol=1e-12)
 
 
+def test_progressive_accumulation_equals_one_launch():
+    """the reference saves randState but never reuses it.  Here 1 + 2 + 1 spp rendered progressively
+    (saved streams + running sums) is bit-identical to one 4-spp launch: same draws, same summation order."""
+    for scene_id, world in ((10, 0), (11, 1), (9, 0)):
+        s = rt.builtin_scene(scene_id, world, W, H)
+        film = rt.Film(W, H)
+        film.render(s, 1, variant=0, flags=8)            # ACCUMULATE (first launch seeds)
+        film.render(s, 2, variant=0, flags=8 | 1)        # ACCUMULATE | KEEP_RNG_STATE
+        film.render(s, 1, variant=0, flags=8 | 1)
+        one, _ = s.render(W, H, 4, variant=0)
+        assert np.array_equal(film.download().view(np.uint64), one.view(np.uint64)), scene_id
+
+
 def test_full_size_rows_match_oracle(oracle):
     """Config C2 geometry (1200x800, list world): pixel RNG sequences depend on the full width, so check
     real rows of the full-size frame at low spp against the oracle."""

@@ -556,6 +556,10 @@ DEV void scan_four(const SphereGeom &g0, const SphereGeom &g1, const SphereGeom 
         c[u] = dot(oc, oc) - g[u]->r2;
         disc[u] = b[u] * b[u] - a * c[u];
     }
+    // Pin the four chains ahead of the branches: without this the compiler sinks each chain next to its own branch
+    // and a wave executes them one after another, every fp64 op waiting for the previous one's result.
+    asm volatile("" : "+v"(disc[0]), "+v"(disc[1]), "+v"(disc[2]), "+v"(disc[3]));
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         if (disc[u] > 0.0 && !(b[u] > 0.0 && c[u] > 0.0)) {  // tmin = 0.001 >= 0: see sphere_test

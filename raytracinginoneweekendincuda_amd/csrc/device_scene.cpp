@@ -3,6 +3,7 @@
 // timing.  Replaces the host driver section R/kernel.cu:675-691.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -197,7 +198,7 @@ rt_film *rt_film_create(int device, int width, int height, int stripe_rows, int 
     if (e == hipSuccess) e = hipMemset(f->own_pixels, 0, np * 3 * sizeof(double));
     f->pixels = f->own_pixels;
     if (e == hipSuccess) e = hipMalloc((void **)&f->state, np * 6 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, device);
@@ -253,7 +254,9 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : f.own_stream;
     const bool keep = (p->flags & RT_FLAG_KEEP_RNG_STATE) && f.seeded;
 
-    HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(f.ray_counter + 2, 0xFF, sizeof(unsigned long long), stream));  // stamp slots (diagnostic builds): min
+    HIP_TRY(hipMemsetAsync(f.ray_counter + 4, 0xFF, 2 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(f.ev[0], stream));
     if (!keep) {
         SeedArgs sa{};
@@ -340,6 +343,12 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         HIP_TRY(hipEventElapsedTime(&ms_render, f.ev[1], f.ev[2]));
         unsigned long long rays = 0;
         HIP_TRY(hipMemcpy(&rays, f.ray_counter, sizeof rays, hipMemcpyDeviceToHost));
+        if (std::getenv("RTOW_PRINT_STAMPS")) {  // diagnostic builds (-DRT_STAMP=1): 100 MHz wall-clock ticks
+            unsigned long long st[8];
+            HIP_TRY(hipMemcpy(st, f.ray_counter, sizeof st, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "stamps: start %llu  queue exhausted +%.3f ms  first wave out +%.3f ms  last wave out +%.3f ms\n",
+                         st[5], (st[2] - st[5]) * 1e-5, (st[4] - st[5]) * 1e-5, (st[3] - st[5]) * 1e-5);
+        }
         stats->samples = f.last_samples;
         stats->rays = rays;
         stats->seconds_seed = ms_seed * 1e-3;

@@ -514,6 +514,9 @@ constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenev
 #ifndef RT_SIMPLE_BREAK
 #define RT_SIMPLE_BREAK 0
 #endif
+#ifndef RT_STAMP
+#define RT_STAMP 0  // diagnostic build: wall-clock stamps of queue exhaustion / first and last wave exit
+#endif
 #ifndef RT_BURST
 #define RT_BURST 8
 #endif
@@ -1125,6 +1128,9 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     walk_best.obj = kNone;
     bool walking = false;
 
+#if RT_STAMP
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicMin(a.ray_counter + 5, (unsigned long long)wall_clock64());
+#endif
     for (;;) {
         // A pixel that has used up its ray budget is "overdue": its samples cannot be spread over lanes (one
         // sequential RNG stream per pixel), and at one ray per pixel-parallel pass it would finish long after the
@@ -1152,6 +1158,9 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 if (lane == 0) base = atomicAdd(a.cursor, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base + cnt >= total_slots) exhausted = true;
+#if RT_STAMP
+                if (exhausted && lane == 0) atomicMin(a.ray_counter + 2, (unsigned long long)wall_clock64());
+#endif
                 const uint32_t slot = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (!active && slot < total_slots) {
                     const uint32_t tile = slot >> 6, w = slot & 63u;
@@ -1294,6 +1303,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         }
     }
 
+#if RT_STAMP
+    if (lane == 0) {
+        atomicMax(a.ray_counter + 3, (unsigned long long)wall_clock64());
+        atomicMin(a.ray_counter + 4, (unsigned long long)wall_clock64());  // first wave to finish
+    }
+#endif
     // one atomic per wave for the ray counter
     unsigned long long total = nrays;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);

@@ -73,7 +73,7 @@ def cpu_baseline(wl, budget_s=12.0):
 def measured_traffic(workload, spp, variant):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (FETCH_SIZE x2 +
     WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); only valid for the exact configuration profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_v4_c2_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_final_c2_pmc.json")
     if workload != "c2" or spp != 500 or variant != "fast" or not os.path.exists(path):
         return None
     with open(path) as f:

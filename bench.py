@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="RT_FLAG_* tuning/diagnostic bits")
     ap.add_argument("--shade-batch", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="tuning knob: cap resident workgroups per CU")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="after the headline (one frame after another) also time the same K frames with this many in "
+                         "flight on per-film streams and report it as \"pipelined\" (1 GPU only; 1 = skip)")
     ap.add_argument("--overdue", type=int, default=0, help="tuning knob: rays/sample budget before a pixel goes cooperative")
     args = ap.parse_args()
 
@@ -158,6 +161,36 @@ def main():
     elapsed = time.perf_counter() - t0
     seed_s = st.seconds_seed
 
+    def pipelined(depth):
+        """The same K frames with `depth` of them in flight: film k % depth on its own HIP stream, reaped just before
+        its slot is reused.  The next frame's waves occupy the SIMDs the current frame's tail (a few long pixels) leaves
+        idle.  Reported beside the headline, never as it."""
+        films = [rt.Film(W, H, device=local_rank) for _ in range(depth)]
+        plist = [f.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, stream=0,
+                          coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags,
+                          shade_batch=args.shade_batch, max_blocks_per_cu=args.blocks_per_cu) for f in films]
+        busy = [False] * depth
+
+        def run(n):
+            for k in range(n):
+                if busy[k % depth]:
+                    films[k % depth].finish(scene)
+                films[k % depth].launch(scene, plist[k % depth])
+                busy[k % depth] = True
+            for k in range(depth):
+                if busy[k]:
+                    films[k].finish(scene)
+                    busy[k] = False
+
+        run(max(args.warmup, depth))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t1
+
+    pipe_elapsed = pipelined(args.pipeline) if (world == 1 and args.pipeline > 1) else None
+
     t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone()
@@ -178,7 +211,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + (f"; {world} GPUs: {W}x{H} (same view, {world}x rows), 8-row stripes round-robin, one RCCL gather"
                                            if world > 1 else ""),
-                       "width": W, "height": H, "spp": spp, "max_depth": 50, "seed": 1984, "variant": args.variant,
+                       "frames_in_flight": 1, "width": W, "height": H, "spp": spp, "max_depth": 50, "seed": 1984, "variant": args.variant,
                        "rng": "XORWOW (cuRAND device-API semantics), one sequence per pixel"},
             "mray_per_s_total": total_rays / (elapsed / args.steps) * 1e-6,
             "mray_per_s_per_gpu": total_rays / world / (elapsed / args.steps) * 1e-6,
@@ -186,6 +219,11 @@ def main():
             "kernel": {"name": "render_kernel", "avg_ms": float(np.mean(kernel_s)) * 1e3, "seed_ms": seed_s * 1e3,
                        "vgprs": st.kernel_vgprs, "lds_bytes": st.lds_bytes},
         }
+        if pipe_elapsed is not None:
+            out["pipelined"] = {"frames_in_flight": args.pipeline, "value": samples_per_step * args.steps / pipe_elapsed * 1e-6,
+                                "unit": "Msamples/s", "ms_per_step": pipe_elapsed / args.steps * 1e3,
+                                "note": "same K frames, launched on per-film HIP streams so that frame k+1 fills the SIMDs "
+                                        "frame k's tail leaves idle; a throughput mode for frame sequences, not the headline"}
         bytes_per_ray = None
         info_spheres = scene.info()["n_spheres"] if world_kind == 1 else 0
         if world == 1 and not args.no_cpu_baseline:

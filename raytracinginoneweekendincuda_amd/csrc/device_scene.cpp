@@ -104,7 +104,8 @@ struct FilmImpl {
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // begin, after seed, after render
+    unsigned long long *host_counters = nullptr;  // pinned mirror of ray_counter, filled by an async copy behind the render
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // begin, after seed, after render, after the counter copy
     bool seeded = false;
     bool in_flight = false;
     uint64_t last_samples = 0;
@@ -205,7 +206,8 @@ rt_film *rt_film_create(int device, int width, int height, int stripe_rows, int 
         if (e == hipSuccess) f->num_cus = prop.multiProcessorCount;
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking);
-    for (int k = 0; k < 3 && e == hipSuccess; k++) e = hipEventCreate(&f->ev[k]);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&f->host_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&f->ev[k]);
     if (e != hipSuccess) {
         hip_fail(e, "rt_film_create allocation");
         rt_film_destroy(reinterpret_cast<rt_film *>(f));
@@ -223,7 +225,8 @@ void rt_film_destroy(rt_film *film)
     if (f->accum) hipFree(f->accum);
     if (f->state) hipFree(f->state);
     if (f->ray_counter) hipFree(f->ray_counter);
-    for (int k = 0; k < 3; k++)
+    if (f->host_counters) hipHostFree(f->host_counters);
+    for (int k = 0; k < 4; k++)
         if (f->ev[k]) hipEventDestroy(f->ev[k]);
     if (f->own_stream) hipStreamDestroy(f->own_stream);
     delete f;
@@ -320,6 +323,10 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
     HIP_TRY(p->variant ? launch_render_fast(ds, ra, stream) : launch_render_strict(ds, ra, stream));
     HIP_TRY(hipEventRecord(f.ev[2], stream));
+    // The counters come home on the film's own stream: a blocking hipMemcpy in rt_render_finish would wait for every
+    // other film's frame as well and serialise frames that were launched to overlap.
+    HIP_TRY(hipMemcpyAsync(f.host_counters, f.ray_counter, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(f.ev[3], stream));
     f.last_stream = stream;
     f.in_flight = true;
     f.last_samples = (uint64_t)f.n_pixels * (uint64_t)p->samples_per_pixel;
@@ -334,18 +341,16 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
     FilmImpl &f = *F(film);
     if (!f.in_flight) return fail(RT_ERR_STATE, "rt_render_finish: nothing launched");
     if (int rc = select_device(f.device)) return rc;
-    HIP_TRY(hipEventSynchronize(f.ev[2]));
+    HIP_TRY(hipEventSynchronize(f.ev[3]));
     f.in_flight = false;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         float ms_seed = 0, ms_render = 0;
         HIP_TRY(hipEventElapsedTime(&ms_seed, f.ev[0], f.ev[1]));
         HIP_TRY(hipEventElapsedTime(&ms_render, f.ev[1], f.ev[2]));
-        unsigned long long rays = 0;
-        HIP_TRY(hipMemcpy(&rays, f.ray_counter, sizeof rays, hipMemcpyDeviceToHost));
+        const unsigned long long rays = f.host_counters[0];
         if (std::getenv("RTOW_PRINT_STAMPS")) {  // diagnostic builds (-DRT_STAMP=1): 100 MHz wall-clock ticks
-            unsigned long long st[8];
-            HIP_TRY(hipMemcpy(st, f.ray_counter, sizeof st, hipMemcpyDeviceToHost));
+            const unsigned long long *st = f.host_counters;
             std::fprintf(stderr, "stamps: start %llu  queue exhausted +%.3f ms  first wave out +%.3f ms  last wave out +%.3f ms\n",
                          st[5], (st[2] - st[5]) * 1e-5, (st[4] - st[5]) * 1e-5, (st[3] - st[5]) * 1e-5);
         }

@@ -113,6 +113,21 @@ def test_progressive_accumulation_equals_one_launch():
         assert np.array_equal(film.download().view(np.uint64), one.view(np.uint64)), scene_id
 
 
+def test_frames_in_flight_on_separate_films_are_independent():
+    """Three films launched back to back on their own streams (frames overlap on the chip: the tail of one is filled by the
+    next) give exactly the frames they give one at a time; each film's ray counter is its own."""
+    jobs = [(10, 0, 3), (11, 1, 2), (7, 0, 2)]
+    scenes = [rt.builtin_scene(sid, wk, W, H) for sid, wk, _ in jobs]
+    films = [rt.Film(W, H) for _ in jobs]
+    for s, f, (_, _, spp) in zip(scenes, films, jobs):
+        f.launch(s, f.params(spp, variant=0))
+    stats = [f.finish(s) for s, f in zip(scenes, films)]
+    for s, f, st, (sid, _, spp) in zip(scenes, films, stats, jobs):
+        alone, st_alone = s.render(W, H, spp, variant=0)
+        assert np.array_equal(f.download().view(np.uint64), alone.view(np.uint64)), sid
+        assert st.rays == st_alone.rays, sid
+
+
 def test_full_size_rows_match_oracle(oracle):
     """Config C2 geometry (1200x800, list world): pixel RNG sequences depend on the full width, so check
     real rows of the full-size frame at low spp against the oracle."""

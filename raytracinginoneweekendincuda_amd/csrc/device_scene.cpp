@@ -90,6 +90,8 @@ static int select_device(int device)
     return RT_OK;
 }
 
+constexpr size_t kCounterWords = 32;
+
 struct FilmImpl {
     int device = 0;
     int width = 0, height = 0, stripe_rows = 8, rank = 0, world_size = 1;
@@ -100,7 +102,7 @@ struct FilmImpl {
     double *accum = nullptr;       // progressive rendering: unnormalised colour sums (allocated on first use)
     int accum_spp = 0;
     uint32_t *state = nullptr;
-    unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor
+    unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor, [2..5] stamps, [8..20] phase sums
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
@@ -199,14 +201,14 @@ rt_film *rt_film_create(int device, int width, int height, int stripe_rows, int 
     if (e == hipSuccess) e = hipMemset(f->own_pixels, 0, np * 3 * sizeof(double));
     f->pixels = f->own_pixels;
     if (e == hipSuccess) e = hipMalloc((void **)&f->state, np * 6 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->ray_counter, kCounterWords * sizeof(unsigned long long));
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, device);
         if (e == hipSuccess) f->num_cus = prop.multiProcessorCount;
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&f->host_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&f->host_counters, kCounterWords * sizeof(unsigned long long), hipHostMallocDefault);
     for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&f->ev[k]);
     if (e != hipSuccess) {
         hip_fail(e, "rt_film_create allocation");
@@ -257,7 +259,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : f.own_stream;
     const bool keep = (p->flags & RT_FLAG_KEEP_RNG_STATE) && f.seeded;
 
-    HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(f.ray_counter, 0, kCounterWords * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(f.ray_counter + 2, 0xFF, sizeof(unsigned long long), stream));  // stamp slots (diagnostic builds): min
     HIP_TRY(hipMemsetAsync(f.ray_counter + 4, 0xFF, 2 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(f.ev[0], stream));
@@ -325,7 +327,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     HIP_TRY(hipEventRecord(f.ev[2], stream));
     // The counters come home on the film's own stream: a blocking hipMemcpy in rt_render_finish would wait for every
     // other film's frame as well and serialise frames that were launched to overlap.
-    HIP_TRY(hipMemcpyAsync(f.host_counters, f.ray_counter, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(f.host_counters, f.ray_counter, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(f.ev[3], stream));
     f.last_stream = stream;
     f.in_flight = true;
@@ -353,6 +355,15 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
             const unsigned long long *st = f.host_counters;
             std::fprintf(stderr, "stamps: start %llu  queue exhausted +%.3f ms  first wave out +%.3f ms  last wave out +%.3f ms\n",
                          st[5], (st[2] - st[5]) * 1e-5, (st[4] - st[5]) * 1e-5, (st[3] - st[5]) * 1e-5);
+        }
+        if (std::getenv("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
+            const unsigned long long *c = f.host_counters;
+            static const char *name[4] = {"node step", "leaf test", "shade", "refill"};
+            const double total = (double)c[20];
+            for (int k = 0; k < 4; k++)
+                std::fprintf(stderr, "phase %-9s: %5.1f %% of wave time, %10llu passes, %5.1f lanes/pass, %7.0f cycles/pass\n", name[k],
+                             100.0 * c[8 + k] / total, c[16 + k], c[16 + k] ? (double)c[12 + k] / c[16 + k] : 0.0,
+                             c[16 + k] ? (double)c[8 + k] / c[16 + k] : 0.0);
         }
         stats->samples = f.last_samples;
         stats->rays = rays;

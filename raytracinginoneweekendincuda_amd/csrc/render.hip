@@ -514,6 +514,21 @@ constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenev
 #ifndef RT_SIMPLE_BREAK
 #define RT_SIMPLE_BREAK 0
 #endif
+#ifndef RT_PHASES
+#define RT_PHASES 0  // diagnostic build: per-phase wave cycles and lane occupancy, summed into ray_counter[8..]
+#endif
+#if RT_PHASES
+#define PH_BEGIN() const unsigned long long ph_t0 = __builtin_readcyclecounter()
+#define PH_END(k, cond)                                                   \
+    do {                                                                  \
+        ph_t[k] += __builtin_readcyclecounter() - ph_t0;                  \
+        ph_l[k] += (unsigned long long)__popcll(__ballot(cond));          \
+        ph_n[k] += 1ull;                                                  \
+    } while (0)
+#else
+#define PH_BEGIN() do { } while (0)
+#define PH_END(k, cond) do { } while (0)
+#endif
 #ifndef RT_STAMP
 #define RT_STAMP 0  // diagnostic build: wall-clock stamps of queue exhaustion / first and last wave exit
 #endif
@@ -1131,6 +1146,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
 #if RT_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicMin(a.ray_counter + 5, (unsigned long long)wall_clock64());
 #endif
+#if RT_PHASES
+    unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_l[4] = {0, 0, 0, 0}, ph_n[4] = {0, 0, 0, 0};  // node, leaf, shade, refill
+    const unsigned long long ph_start = __builtin_readcyclecounter();
+#endif
     for (;;) {
         // A pixel that has used up its ray budget is "overdue": its samples cannot be spread over lanes (one
         // sequential RNG stream per pixel), and at one ray per pixel-parallel pass it would finish long after the
@@ -1153,6 +1172,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         if (!exhausted && !boost) {
             const unsigned long long need = __ballot(!active);
             if (need) {
+                PH_BEGIN();
+                [[maybe_unused]] const bool ph_was_idle = !active;
                 const uint32_t cnt = (uint32_t)__popcll(need);
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(a.cursor, cnt);
@@ -1192,6 +1213,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         }
                     }
                 }
+                PH_END(3, ph_was_idle && active);
             }
         }
         const unsigned long long live = __ballot(active);
@@ -1231,14 +1253,23 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                     const int parked = __popcll(__ballot(walking && walk.at_leaves));
                     if (movers == 0 || movers < parked) break;  // most walkers are waiting at leaves: go test them
 #endif
-                    if (mover) {
-                        walk_node(nv, ray, 0.001, walk);
-                        walking = walk.node != kNone;
+                    {
+                        PH_BEGIN();
+                        if (mover) {
+                            walk_node(nv, ray, 0.001, walk);
+                            walking = walk.node != kNone;
+                        }
+                        PH_END(0, mover);
                     }
                 }
-                if (walking && walk.at_leaves) {
-                    walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng);
-                    walking = walk.node != kNone;
+                {
+                    const bool at_leaf = walking && walk.at_leaves;
+                    PH_BEGIN();
+                    if (at_leaf) {
+                        walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng);
+                        walking = walk.node != kNone;
+                    }
+                    if (__any(at_leaf)) PH_END(1, at_leaf);
                 }
                 if (!__any(walking)) break;
             }
@@ -1249,6 +1280,9 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             hit = walk.any;
             h = walk_best;
         }
+#if RT_PHASES
+        const unsigned long long ph_ts = __builtin_readcyclecounter();
+#endif
         if ((todo >> lane) & 1ull) {
             const bool no_bounces = a.max_depth <= 0;  // R/kernel.cu:71: the bounce loop never runs, RayColor returns black
             if (!no_bounces) {
@@ -1301,7 +1335,24 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 }
             }
         }
+#if RT_PHASES
+        if (todo) {
+            ph_t[2] += __builtin_readcyclecounter() - ph_ts;
+            ph_l[2] += (unsigned long long)__popcll(todo);
+            ph_n[2] += 1ull;
+        }
+#endif
     }
+#if RT_PHASES
+    if (lane == 0) {
+        for (int k = 0; k < 4; k++) {
+            atomicAdd(a.ray_counter + 8 + k, ph_t[k]);
+            atomicAdd(a.ray_counter + 12 + k, ph_l[k]);
+            atomicAdd(a.ray_counter + 16 + k, ph_n[k]);
+        }
+        atomicAdd(a.ray_counter + 20, __builtin_readcyclecounter() - ph_start);
+    }
+#endif
 
 #if RT_STAMP
     if (lane == 0) {

@@ -102,7 +102,7 @@ struct FilmImpl {
     double *accum = nullptr;       // progressive rendering: unnormalised colour sums (allocated on first use)
     int accum_spp = 0;
     uint32_t *state = nullptr;
-    unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor, [2..5] stamps, [8..20] phase sums
+    unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor, [2..5] stamps, [7..31] phase sums
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
@@ -358,12 +358,12 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         }
         if (std::getenv("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;
-            static const char *name[4] = {"node step", "leaf test", "shade", "refill"};
-            const double total = (double)c[20];
-            for (int k = 0; k < 4; k++)
-                std::fprintf(stderr, "phase %-9s: %5.1f %% of wave time, %10llu passes, %5.1f lanes/pass, %7.0f cycles/pass\n", name[k],
-                             100.0 * c[8 + k] / total, c[16 + k], c[16 + k] ? (double)c[12 + k] / c[16 + k] : 0.0,
-                             c[16 + k] ? (double)c[8 + k] / c[16 + k] : 0.0);
+            static const char *name[7] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive"};
+            const double total = (double)c[7];
+            for (int k = 0; k < 7; k++)
+                std::fprintf(stderr, "phase %-16s: %5.1f %% of wave time, %10llu passes, %5.1f lanes/pass, %7.0f cycles/pass\n", name[k],
+                             100.0 * c[8 + k] / total, c[24 + k], c[24 + k] ? (double)c[16 + k] / c[24 + k] : 0.0,
+                             c[24 + k] ? (double)c[8 + k] / c[24 + k] : 0.0);
         }
         stats->samples = f.last_samples;
         stats->rays = rays;

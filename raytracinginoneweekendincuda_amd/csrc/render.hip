@@ -207,6 +207,39 @@ DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
     }
 }
 
+#ifndef RT_PHASES
+#define RT_PHASES 0  // diagnostic build: per-phase wave cycles and lane occupancy, summed into ray_counter[8..]
+#endif
+#if RT_PHASES
+#define PH_BEGIN() const unsigned long long ph_t0 = __builtin_readcyclecounter()
+#define PH_END(k, cond)                                                   \
+    do {                                                                  \
+        ph.t[k] += __builtin_readcyclecounter() - ph_t0;                  \
+        ph.l[k] += (unsigned long long)__popcll(__ballot(cond));          \
+        ph.n[k] += 1ull;                                                  \
+    } while (0)
+struct PhaseSums {
+    unsigned long long t[8], l[8], n[8];  // 0 node, 1 leaf, 2 shade, 3 refill; inside the leaf phase: 4 group/instance, 5 medium, 6 primitive
+};
+#define PH_ARG , PhaseSums &ph
+#define PH_PASS , ph
+#define PH_SUB_BEGIN() const unsigned long long ph_s0 = __builtin_readcyclecounter()
+// inside divergent control flow the sums are per lane: each lane books its share (x1024), the wave adds them up at the end
+#define PH_SUB_END(k)                                                                              \
+    do {                                                                                           \
+        const unsigned long long ph_pc = (unsigned long long)__popcll(__ballot(true));             \
+        ph.t[k] += (__builtin_readcyclecounter() - ph_s0) * 1024ull / ph_pc;                       \
+        ph.l[k] += 1024ull;                                                                        \
+        ph.n[k] += 1024ull / ph_pc;                                                                \
+    } while (0)
+#else
+#define PH_BEGIN() do { } while (0)
+#define PH_END(k, cond) do { } while (0)
+#define PH_ARG
+#define PH_PASS
+#define PH_SUB_BEGIN() do { } while (0)
+#define PH_SUB_END(k) do { } while (0)
+#endif
 // Ray into the object space of a composite leaf: Translate (R/Instance.h:46) and RotateY (:121-131)
 // applied outermost first.
 DEV Ray to_object_space(const DeviceScene &sc, const ObjectRec &o, const Ray &r)
@@ -370,24 +403,34 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     return true;
 }
 
-template <class T>
-DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng)
-{
-    if constexpr (T::COMPOSITE) {
-        if ((ref >> kRefShift) == REF_OBJECT) return object_test<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
-    }
-    double t;
-    if (!prim_test(sc, ref, r, a, tmin, tmax, t)) return false;
-    best.t = t;
-    best.ref = ref;
-    best.obj = kNone;
-    return true;
-}
-
 DEV bool is_medium_leaf(const DeviceScene &sc, uint32_t ref)
 {
     return (ref >> kRefShift) == REF_OBJECT && sc.objects[ref & kRefIndexMask].medium != kNone;
 }
+
+template <class T>
+DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
+{
+    if constexpr (T::COMPOSITE) {
+        if ((ref >> kRefShift) == REF_OBJECT) {
+            PH_SUB_BEGIN();
+            const bool found = object_test<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
+            PH_SUB_END(is_medium_leaf(sc, ref) ? 5 : 4);
+            return found;
+        }
+    }
+    PH_SUB_BEGIN();
+    double t;
+    const bool found = prim_test(sc, ref, r, a, tmin, tmax, t);
+    if (found) {
+        best.t = t;
+        best.ref = ref;
+        best.obj = kNone;
+    }
+    PH_SUB_END(6);
+    return found;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // world traversal
@@ -460,7 +503,7 @@ DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
 
 // Leaf phase for a parked lane: the bottom node's one or two leaves, in the reference's order.
 template <class T>
-DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng)
+DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng PH_ARG)
 {
     const uint32_t n = w.node;
     uint32_t na, nb, next;
@@ -476,7 +519,7 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
     if constexpr (T::MEDIA) again = again || is_medium_leaf(sc, nb);
     for (int c = 0; c < 2; c++) {  // one inlined copy of the leaf test
         if (c == 1 && !again) break;
-        if (leaf_test<T>(sc, c ? nb : na, r, w.a, tmin, w.closest, best, rng)) {
+        if (leaf_test<T>(sc, c ? nb : na, r, w.a, tmin, w.closest, best, rng PH_PASS)) {
             w.any = true;
             w.closest = best.t;
         }
@@ -488,7 +531,7 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
 // HittableList world (R/HittableList.h:39-57): the item index is wave-uniform, so the primitive rows
 // are fetched through the scalar path.
 template <class T>
-DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng)
+DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
 {
     double a = dot(r.d, r.d);
     double closest = tmax;
@@ -496,7 +539,7 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
     const uint32_t n = sc.n_world_items;
     for (uint32_t k = 0; k < n; k++) {
         uint32_t ref = sc.world_items[k];
-        if (leaf_test<T>(sc, ref, r, a, tmin, closest, best, rng)) {
+        if (leaf_test<T>(sc, ref, r, a, tmin, closest, best, rng PH_PASS)) {
             any = true;
             closest = best.t;
         }
@@ -513,21 +556,6 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
 constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenever a lane could overflow
 #ifndef RT_SIMPLE_BREAK
 #define RT_SIMPLE_BREAK 0
-#endif
-#ifndef RT_PHASES
-#define RT_PHASES 0  // diagnostic build: per-phase wave cycles and lane occupancy, summed into ray_counter[8..]
-#endif
-#if RT_PHASES
-#define PH_BEGIN() const unsigned long long ph_t0 = __builtin_readcyclecounter()
-#define PH_END(k, cond)                                                   \
-    do {                                                                  \
-        ph_t[k] += __builtin_readcyclecounter() - ph_t0;                  \
-        ph_l[k] += (unsigned long long)__popcll(__ballot(cond));          \
-        ph_n[k] += 1ull;                                                  \
-    } while (0)
-#else
-#define PH_BEGIN() do { } while (0)
-#define PH_END(k, cond) do { } while (0)
 #endif
 #ifndef RT_STAMP
 #define RT_STAMP 0  // diagnostic build: wall-clock stamps of queue exhaustion / first and last wave exit
@@ -1147,7 +1175,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicMin(a.ray_counter + 5, (unsigned long long)wall_clock64());
 #endif
 #if RT_PHASES
-    unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_l[4] = {0, 0, 0, 0}, ph_n[4] = {0, 0, 0, 0};  // node, leaf, shade, refill
+    PhaseSums ph{};
     const unsigned long long ph_start = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -1266,7 +1294,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                     const bool at_leaf = walking && walk.at_leaves;
                     PH_BEGIN();
                     if (at_leaf) {
-                        walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng);
+                        walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng PH_PASS);
                         walking = walk.node != kNone;
                     }
                     if (__any(at_leaf)) PH_END(1, at_leaf);
@@ -1289,7 +1317,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 nrays++;
                 pix_rays++;
             }
-            if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng);
+            if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng PH_PASS);
             bool path_ends;
             if (no_bounces) {
                 path_ends = true;
@@ -1337,20 +1365,30 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         }
 #if RT_PHASES
         if (todo) {
-            ph_t[2] += __builtin_readcyclecounter() - ph_ts;
-            ph_l[2] += (unsigned long long)__popcll(todo);
-            ph_n[2] += 1ull;
+            ph.t[2] += __builtin_readcyclecounter() - ph_ts;
+            ph.l[2] += (unsigned long long)__popcll(todo);
+            ph.n[2] += 1ull;
         }
 #endif
     }
 #if RT_PHASES
-    if (lane == 0) {
-        for (int k = 0; k < 4; k++) {
-            atomicAdd(a.ray_counter + 8 + k, ph_t[k]);
-            atomicAdd(a.ray_counter + 12 + k, ph_l[k]);
-            atomicAdd(a.ray_counter + 16 + k, ph_n[k]);
+    for (int k = 4; k < 8; k++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            ph.t[k] += __shfl_down(ph.t[k], off, 64);
+            ph.l[k] += __shfl_down(ph.l[k], off, 64);
+            ph.n[k] += __shfl_down(ph.n[k], off, 64);
         }
-        atomicAdd(a.ray_counter + 20, __builtin_readcyclecounter() - ph_start);
+        ph.t[k] >>= 10;
+        ph.l[k] >>= 10;
+        ph.n[k] >>= 10;
+    }
+    if (lane == 0) {
+        for (int k = 0; k < 8; k++) {
+            atomicAdd(a.ray_counter + 8 + k, ph.t[k]);
+            atomicAdd(a.ray_counter + 16 + k, ph.l[k]);
+            atomicAdd(a.ray_counter + 24 + k, ph.n[k]);
+        }
+        atomicAdd(a.ray_counter + 7, __builtin_readcyclecounter() - ph_start);
     }
 #endif
 

@@ -145,6 +145,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.mspheres, d.mspheres);
     up(f.msphere_aux, d.msphere_aux);
     up(f.quads, d.quads);
+    up(f.quad_aa, d.quad_aa);
     up(f.quad_mat, d.quad_mat);
     up(f.objects, d.objects);
     up(f.items, d.items);

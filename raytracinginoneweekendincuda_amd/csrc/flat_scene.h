@@ -33,6 +33,13 @@ struct MSphereGeom { double c0x, c0y, c0z, dcx, dcy, dcz, t0, dt, r2; };
 
 // Quad (R/Quad.h:25-49): plane n.x = d, w = n / (n.n) for the planar coordinates.
 struct QuadGeom { double qx, qy, qz, ux, uy, uz, vx, vy, vz, wx, wy, wz, nx, ny, nz, d; };
+// The same quad when u and v each lie along one coordinate axis (every quad MakeBox and the reference's scenes
+// build): normal and w then have a single non-zero component, every other term of R/Quad.h:52-99's dot and cross
+// products is an exact zero, and t / alpha / beta come out of one multiply each -- the same bits as the general
+// test.  a = axis of the normal, p = axis of u, q = axis of v:
+//   t = (d - na*o[a]) / (na*dir[a]);  ph = (o + t*dir) - Q;  alpha = wa*(ph[p]*kv);  beta = wa*(ku*ph[q])
+// with kv = +-v[q], ku = +-u[p] (the sign of that term in the cross product).
+struct AAQuad { double na, d, wa, qp, qq, ku, kv; uint32_t code, pad; };  // code 0: not axis-aligned; else 1 + 3a + p
 
 // Instance transform step (R/Instance.h:31-37 Translate, :74-112 RotateY).
 enum : uint32_t { XF_TRANSLATE = 0u, XF_ROTATE_Y = 1u };
@@ -40,7 +47,8 @@ struct Xform { double a, b, c; uint32_t kind; uint32_t pad; };  // translate: of
 
 // Composite leaf: [ConstantMedium] -> chain of Translate/RotateY (outermost first) -> geometry.
 enum : uint32_t { GEOM_SINGLE = 0u, GEOM_SPHERES = 1u, GEOM_MSPHERES = 2u, GEOM_QUADS = 3u, GEOM_MIXED = 4u,
-                  GEOM_BVH = 5u };  // GEOM_BVH: `first` = root of a sub-BVH (in nodes[]) over the group's primitives
+                  GEOM_BVH = 5u,    // `first` = root of a sub-BVH (in nodes[]) over the group's primitives
+                  GEOM_BOX = 6u };  // six axis-aligned quads with MakeBox's face axes (R/Instance.h:166-184): `first` = first quad
 constexpr uint32_t kSubBvhMinPrims = 16;  // groups at least this large get a sub-BVH
 struct ObjectRec {
     uint32_t geom_kind;  // GEOM_*
@@ -91,6 +99,7 @@ struct DeviceScene {
     const MSphereGeom *mspheres;
     const SphereAux *msphere_aux;
     const QuadGeom *quads;
+    const AAQuad *quad_aa;        // parallel to quads
     const uint32_t *quad_mat;
     const ObjectRec *objects;
     const uint32_t *items;        // GEOM_MIXED entries (prim refs)

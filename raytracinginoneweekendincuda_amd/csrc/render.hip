@@ -182,6 +182,84 @@ DEV bool quad_test(const QuadGeom &q, const Ray &r, double tmin, double tmax, do
     return true;
 }
 
+// Axis-aligned quads (AAQuad, flat_scene.h): the same t, alpha and beta as quad_test, without the terms that are exact zeros.
+template <int K>
+DEV double comp(const Vec &v)
+{
+    return K == 0 ? v.x : (K == 1 ? v.y : v.z);
+}
+template <int A>
+DEV bool aa_plane(double na, double d, const Ray &r, double tmin, double tmax, double &t)
+{
+    double denom = na * comp<A>(r.d);
+    t = (d - na * comp<A>(r.o)) / denom;
+    return !(fabs(denom) < 1e-8) && !(t < tmin || t > tmax);
+}
+template <int P, int Q>
+DEV bool aa_inside(double wa, double qp, double qq, double ku, double kv, const Ray &r, double t)
+{
+    double php = (comp<P>(r.o) + t * comp<P>(r.d)) - qp;
+    double phq = (comp<Q>(r.o) + t * comp<Q>(r.d)) - qq;
+    double alpha = wa * (php * kv);
+    double beta = wa * (ku * phq);
+    return (0.0 <= alpha && alpha <= 1.0) && (0.0 <= beta && beta <= 1.0);
+}
+template <int A, int P>
+DEV bool aa_quad_test(const AAQuad &q, const Ray &r, double tmin, double tmax, double &t_out)
+{
+    double t;
+    if (!aa_plane<A>(q.na, q.d, r, tmin, tmax, t)) return false;
+    if (!aa_inside<P, 3 - A - P>(q.wa, q.qp, q.qq, q.ku, q.kv, r, t)) return false;
+    t_out = t;
+    return true;
+}
+DEV bool quad_test_at(const DeviceScene &sc, uint32_t idx, const Ray &r, double tmin, double tmax, double &t)
+{
+    const AAQuad q = sc.quad_aa[idx];
+    switch (q.code) {
+    case 1 + 3 * 0 + 1: return aa_quad_test<0, 1>(q, r, tmin, tmax, t);
+    case 1 + 3 * 0 + 2: return aa_quad_test<0, 2>(q, r, tmin, tmax, t);
+    case 1 + 3 * 1 + 0: return aa_quad_test<1, 0>(q, r, tmin, tmax, t);
+    case 1 + 3 * 1 + 2: return aa_quad_test<1, 2>(q, r, tmin, tmax, t);
+    case 1 + 3 * 2 + 0: return aa_quad_test<2, 0>(q, r, tmin, tmax, t);
+    case 1 + 3 * 2 + 1: return aa_quad_test<2, 1>(q, r, tmin, tmax, t);
+    default: return quad_test(sc.quads[idx], r, tmin, tmax, t);
+    }
+}
+
+// MakeBox (R/Instance.h:166-184) as HittableList::Hit sees it (R/HittableList.h:39-57): six faces in list order
+// against one running closest-so-far.  The six plane distances do not depend on each other, so they are evaluated
+// together (six divides in flight instead of one after another); the interior tests then run in list order.
+DEV bool box_closest(const AAQuad *faces, const Ray &r, double tmin, double tmax, double &t_best, uint32_t &face_best)
+{
+    double t[6];
+    bool ok[6];
+    ok[0] = aa_plane<2>(faces[0].na, faces[0].d, r, tmin, tmax, t[0]);  // front
+    ok[1] = aa_plane<0>(faces[1].na, faces[1].d, r, tmin, tmax, t[1]);  // right
+    ok[2] = aa_plane<2>(faces[2].na, faces[2].d, r, tmin, tmax, t[2]);  // back
+    ok[3] = aa_plane<0>(faces[3].na, faces[3].d, r, tmin, tmax, t[3]);  // left
+    ok[4] = aa_plane<1>(faces[4].na, faces[4].d, r, tmin, tmax, t[4]);  // top
+    ok[5] = aa_plane<1>(faces[5].na, faces[5].d, r, tmin, tmax, t[5]);  // bottom
+    double closest = tmax;
+    bool any = false;
+#define RT_BOX_FACE(k, P, Q)                                                                                              \
+    if (ok[k] && !(t[k] > closest) &&                                                                                     \
+        aa_inside<P, Q>(faces[k].wa, faces[k].qp, faces[k].qq, faces[k].ku, faces[k].kv, r, t[k])) {                      \
+        closest = t[k];                                                                                                   \
+        face_best = k;                                                                                                    \
+        any = true;                                                                                                       \
+    }
+    RT_BOX_FACE(0, 0, 1)
+    RT_BOX_FACE(1, 2, 1)
+    RT_BOX_FACE(2, 0, 1)
+    RT_BOX_FACE(3, 2, 1)
+    RT_BOX_FACE(4, 0, 2)
+    RT_BOX_FACE(5, 0, 2)
+#undef RT_BOX_FACE
+    t_best = closest;
+    return any;
+}
+
 // unit_time: every row has time0 = 0 and time1 - time0 = 1, so (tm - 0) / 1 == tm exactly and the divide is skipped
 DEV Vec msphere_center(const MSphereGeom &g, double tm, bool unit_time = false)  // R/MovingSphere.h:51-52
 {
@@ -202,7 +280,7 @@ DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
         return sphere_test(r.o - msphere_center(g, r.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0), r.d, a, g.r2, tmin, tmax, t);
     }
     default: {
-        return quad_test(sc.quads[idx], r, tmin, tmax, t);
+        return quad_test_at(sc, idx, r, tmin, tmax, t);
     }
     }
 }
@@ -335,10 +413,16 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
             }
         }
         break;
+    case GEOM_BOX: {
+        uint32_t face = 0;
+        any = box_closest(sc.quad_aa + o.first, lr, tmin, tmax, closest, face);
+        if (any) ref_best = make_ref(REF_QUAD, o.first + face);
+        break;
+    }
     case GEOM_QUADS:
         for (uint32_t k = 0; k < o.count; k++) {
             double t;
-            if (quad_test(sc.quads[o.first + k], lr, tmin, closest, t)) {
+            if (quad_test_at(sc, o.first + k, lr, tmin, closest, t)) {
                 any = true;
                 closest = t;
                 ref_best = make_ref(REF_QUAD, o.first + k);

@@ -277,8 +277,40 @@ struct Flattener {
         }
         f.quads.push_back({h.q.x, h.q.y, h.q.z, h.u.x, h.u.y, h.u.z, h.v.x, h.v.y, h.v.z, h.w.x, h.w.y, h.w.z,
                            h.normal.x, h.normal.y, h.normal.z, h.plane_d});
+        f.quad_aa.push_back(axis_aligned(f.quads.back()));
         f.quad_mat.push_back(h.material - 1);
         return make_ref(REF_QUAD, (uint32_t)f.quads.size() - 1);
+    }
+
+    // AAQuad of a quad whose edge vectors each lie along one coordinate axis (code 0 otherwise); see flat_scene.h.
+    static AAQuad axis_aligned(const QuadGeom &g)
+    {
+        AAQuad out{};
+        const double u[3] = {g.ux, g.uy, g.uz}, v[3] = {g.vx, g.vy, g.vz}, w[3] = {g.wx, g.wy, g.wz}, n[3] = {g.nx, g.ny, g.nz};
+        const double q[3] = {g.qx, g.qy, g.qz};
+        int p = -1, qa = -1;
+        for (int k = 0; k < 3; k++) {
+            if (u[k] != 0.0) p = p == -1 ? k : -2;
+            if (v[k] != 0.0) qa = qa == -1 ? k : -2;
+        }
+        if (p < 0 || qa < 0 || p == qa) return out;
+        const int a = 3 - p - qa;
+        // everything the shortcut drops must be an exact zero, everything it keeps finite
+        if (n[p] != 0.0 || n[qa] != 0.0 || w[p] != 0.0 || w[qa] != 0.0) return out;
+        if (!std::isfinite(n[a]) || !std::isfinite(w[a]) || !std::isfinite(g.d) || n[a] == 0.0) return out;
+        for (int k = 0; k < 3; k++)
+            if (!std::isfinite(u[k]) || !std::isfinite(v[k]) || !std::isfinite(q[k])) return out;
+        out.na = n[a];
+        out.d = g.d;
+        out.wa = w[a];
+        out.qp = q[p];
+        out.qq = q[qa];
+        // component a of cross(ph, v) is ph[a+1]*v[a+2] - ph[a+2]*v[a+1]; of cross(u, ph): u[a+1]*ph[a+2] - u[a+2]*ph[a+1]
+        const bool p_first = p == (a + 1) % 3;  // (p, q) = (a+1, a+2)
+        out.kv = p_first ? v[qa] : -v[qa];
+        out.ku = p_first ? u[p] : -u[p];
+        out.code = 1u + 3u * (uint32_t)a + (uint32_t)p;
+        return out;
     }
 
     static bool is_primitive(HKind k) { return k == HKind::Sphere || k == HKind::MovingSphere || k == HKind::Quad; }
@@ -375,6 +407,13 @@ struct Flattener {
                 uint32_t first_ref = add_primitive(s.hittables[prims[0] - 1]);
                 obj.first = first_ref & kRefIndexMask;
                 for (size_t k = 1; k < prims.size(); k++) add_primitive(s.hittables[prims[k] - 1]);
+                if (all_q && prims.size() == 6) {
+                    // MakeBox's faces (R/Instance.h:166-184): front, right, back, left, top, bottom
+                    static const uint32_t box_codes[6] = {1 + 3 * 2 + 0, 1 + 3 * 0 + 2, 1 + 3 * 2 + 0, 1 + 3 * 0 + 2, 1 + 3 * 1 + 0, 1 + 3 * 1 + 0};
+                    bool box = true;
+                    for (int k = 0; k < 6; k++) box &= f.quad_aa[obj.first + k].code == box_codes[k];
+                    if (box) obj.geom_kind = GEOM_BOX;
+                }
             } else {
                 obj.geom_kind = GEOM_MIXED;
                 std::vector<uint32_t> refs;

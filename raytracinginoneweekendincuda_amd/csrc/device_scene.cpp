@@ -90,7 +90,7 @@ static int select_device(int device)
     return RT_OK;
 }
 
-constexpr size_t kCounterWords = 32;
+constexpr size_t kCounterWords = 64;
 
 struct FilmImpl {
     int device = 0;
@@ -102,7 +102,7 @@ struct FilmImpl {
     double *accum = nullptr;       // progressive rendering: unnormalised colour sums (allocated on first use)
     int accum_spp = 0;
     uint32_t *state = nullptr;
-    unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor, [2..5] stamps, [7..31] phase sums
+    unsigned long long *ray_counter = nullptr;  // [0] rays, [1] low word = pixel-queue cursor, [2..5] stamps, [7] and [16..63] phase sums
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
@@ -146,6 +146,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.msphere_aux, d.msphere_aux);
     up(f.quads, d.quads);
     up(f.quad_aa, d.quad_aa);
+    up(f.boxes, d.boxes);
     up(f.quad_mat, d.quad_mat);
     up(f.objects, d.objects);
     up(f.items, d.items);
@@ -359,12 +360,14 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         }
         if (std::getenv("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;
-            static const char *name[7] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive"};
+            static const char *name[12] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
+                                           "    record+xforms", "    box", "    sub-BVH", "    other geometry"};
             const double total = (double)c[7];
-            for (int k = 0; k < 7; k++)
-                std::fprintf(stderr, "phase %-16s: %5.1f %% of wave time, %10llu passes, %5.1f lanes/pass, %7.0f cycles/pass\n", name[k],
-                             100.0 * c[8 + k] / total, c[24 + k], c[24 + k] ? (double)c[16 + k] / c[24 + k] : 0.0,
-                             c[24 + k] ? (double)c[8 + k] / c[24 + k] : 0.0);
+            for (int k = 0; k < 12; k++)
+                if (k != 7)
+                    std::fprintf(stderr, "phase %-20s: %5.1f %% of wave time, %10llu passes, %5.1f lanes/pass, %7.0f cycles/pass\n", name[k],
+                                 100.0 * c[16 + k] / total, c[48 + k], c[48 + k] ? (double)c[32 + k] / c[48 + k] : 0.0,
+                                 c[48 + k] ? (double)c[16 + k] / c[48 + k] : 0.0);
         }
         stats->samples = f.last_samples;
         stats->rays = rays;

@@ -40,6 +40,11 @@ struct QuadGeom { double qx, qy, qz, ux, uy, uz, vx, vy, vz, wx, wy, wz, nx, ny,
 //   t = (d - na*o[a]) / (na*dir[a]);  ph = (o + t*dir) - Q;  alpha = wa*(ph[p]*kv);  beta = wa*(ku*ph[q])
 // with kv = +-v[q], ku = +-u[p] (the sign of that term in the cross product).
 struct AAQuad { double na, d, wa, qp, qq, ku, kv; uint32_t code, pad; };  // code 0: not axis-aligned; else 1 + 3a + p
+// MakeBox (R/Instance.h:166-184): the six faces' planes and the two corners.  A face's interior test only decides
+// accept / reject, and alpha = (P[p] - Q[p]) / u[p] up to a few ulps; so a hit point P that is inside [mn, mx] by more
+// than 2^-30 of the coordinates' magnitude is accepted, one that is outside by as much is rejected, and only the
+// sliver in between evaluates the face's own alpha / beta (render.hip box_closest has the bound).
+struct BoxRec { double na[6], d[6], mn[3], mx[3]; uint32_t quad_first, pad; };
 
 // Instance transform step (R/Instance.h:31-37 Translate, :74-112 RotateY).
 enum : uint32_t { XF_TRANSLATE = 0u, XF_ROTATE_Y = 1u };
@@ -48,7 +53,7 @@ struct Xform { double a, b, c; uint32_t kind; uint32_t pad; };  // translate: of
 // Composite leaf: [ConstantMedium] -> chain of Translate/RotateY (outermost first) -> geometry.
 enum : uint32_t { GEOM_SINGLE = 0u, GEOM_SPHERES = 1u, GEOM_MSPHERES = 2u, GEOM_QUADS = 3u, GEOM_MIXED = 4u,
                   GEOM_BVH = 5u,    // `first` = root of a sub-BVH (in nodes[]) over the group's primitives
-                  GEOM_BOX = 6u };  // six axis-aligned quads with MakeBox's face axes (R/Instance.h:166-184): `first` = first quad
+                  GEOM_BOX = 6u };  // six axis-aligned quads that form a MakeBox box: `first` = index into boxes
 constexpr uint32_t kSubBvhMinPrims = 16;  // groups at least this large get a sub-BVH
 struct ObjectRec {
     uint32_t geom_kind;  // GEOM_*
@@ -100,6 +105,7 @@ struct DeviceScene {
     const SphereAux *msphere_aux;
     const QuadGeom *quads;
     const AAQuad *quad_aa;        // parallel to quads
+    const BoxRec *boxes;
     const uint32_t *quad_mat;
     const ObjectRec *objects;
     const uint32_t *items;        // GEOM_MIXED entries (prim refs)

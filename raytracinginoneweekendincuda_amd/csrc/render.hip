@@ -230,24 +230,46 @@ DEV bool quad_test_at(const DeviceScene &sc, uint32_t idx, const Ray &r, double 
 // MakeBox (R/Instance.h:166-184) as HittableList::Hit sees it (R/HittableList.h:39-57): six faces in list order
 // against one running closest-so-far.  The six plane distances do not depend on each other, so they are evaluated
 // together (six divides in flight instead of one after another); the interior tests then run in list order.
-DEV bool box_closest(const AAQuad *faces, const Ray &r, double tmin, double tmax, double &t_best, uint32_t &face_best)
+//
+// Interior test of a face with in-plane axes p, q.  R/Quad.h:86-96 accepts when alpha and beta are in [0, 1], where
+// (AAQuad) alpha = fl(wa * fl(fl(P[p] - Q[p]) * kv)) = (P[p] - Q[p]) / u[p] * (1 + e), |e| < 2^-49, P the hit point
+// as computed.  The host has checked (box_of_six) that Q[p] is mn[p] with u[p] = fl(mx[p] - mn[p]), or mx[p] with the
+// negated extent.  With m = 2^-30 (|mn[p]| + |mx[p]|):
+//   mn[p] + m <= P[p] <= mx[p] - m  =>  2^-30 <= (P[p] - Q[p]) / u[p] <= 1 - 2^-31  =>  alpha in [0, 1] for certain;
+//   P[p] < mn[p] - m or P[p] > mx[p] + m  =>  alpha < 0 or alpha > 1 for certain;
+// the same for beta along q.  Only a hit point inside the 2m sliver around an edge needs alpha / beta themselves.
+DEV bool box_closest(const DeviceScene &sc, const BoxRec *b, const Ray &r, double tmin, double tmax, double &t_best,
+                     uint32_t &ref_best)
 {
     double t[6];
     bool ok[6];
-    ok[0] = aa_plane<2>(faces[0].na, faces[0].d, r, tmin, tmax, t[0]);  // front
-    ok[1] = aa_plane<0>(faces[1].na, faces[1].d, r, tmin, tmax, t[1]);  // right
-    ok[2] = aa_plane<2>(faces[2].na, faces[2].d, r, tmin, tmax, t[2]);  // back
-    ok[3] = aa_plane<0>(faces[3].na, faces[3].d, r, tmin, tmax, t[3]);  // left
-    ok[4] = aa_plane<1>(faces[4].na, faces[4].d, r, tmin, tmax, t[4]);  // top
-    ok[5] = aa_plane<1>(faces[5].na, faces[5].d, r, tmin, tmax, t[5]);  // bottom
+    ok[0] = aa_plane<2>(b->na[0], b->d[0], r, tmin, tmax, t[0]);  // front
+    ok[1] = aa_plane<0>(b->na[1], b->d[1], r, tmin, tmax, t[1]);  // right
+    ok[2] = aa_plane<2>(b->na[2], b->d[2], r, tmin, tmax, t[2]);  // back
+    ok[3] = aa_plane<0>(b->na[3], b->d[3], r, tmin, tmax, t[3]);  // left
+    ok[4] = aa_plane<1>(b->na[4], b->d[4], r, tmin, tmax, t[4]);  // top
+    ok[5] = aa_plane<1>(b->na[5], b->d[5], r, tmin, tmax, t[5]);  // bottom
+    const Vec mn = mk(b->mn[0], b->mn[1], b->mn[2]), mx = mk(b->mx[0], b->mx[1], b->mx[2]);
+    const double k30 = 9.313225746154785e-10;  // 2^-30
+    const Vec m = mk(k30 * (fabs(mn.x) + fabs(mx.x)), k30 * (fabs(mn.y) + fabs(mx.y)), k30 * (fabs(mn.z) + fabs(mx.z)));
+    const Vec in_lo = mn + m, in_hi = mx - m, out_lo = mn - m, out_hi = mx + m;
+    const uint32_t quad_first = b->quad_first;
     double closest = tmax;
     bool any = false;
-#define RT_BOX_FACE(k, P, Q)                                                                                              \
-    if (ok[k] && !(t[k] > closest) &&                                                                                     \
-        aa_inside<P, Q>(faces[k].wa, faces[k].qp, faces[k].qq, faces[k].ku, faces[k].kv, r, t[k])) {                      \
-        closest = t[k];                                                                                                   \
-        face_best = k;                                                                                                    \
-        any = true;                                                                                                       \
+#define RT_BOX_FACE(k, P, Q)                                                                                            \
+    if (ok[k] && !(t[k] > closest)) {                                                                                   \
+        const double pp = comp<P>(r.o) + t[k] * comp<P>(r.d), pq = comp<Q>(r.o) + t[k] * comp<Q>(r.d);                  \
+        bool accept = pp >= comp<P>(in_lo) && pp <= comp<P>(in_hi) && pq >= comp<Q>(in_lo) && pq <= comp<Q>(in_hi);     \
+        const bool outside = pp < comp<P>(out_lo) || pp > comp<P>(out_hi) || pq < comp<Q>(out_lo) || pq > comp<Q>(out_hi); \
+        if (!accept && !outside) {                                                                                      \
+            const AAQuad f = sc.quad_aa[quad_first + k];                                                                \
+            accept = aa_inside<P, Q>(f.wa, f.qp, f.qq, f.ku, f.kv, r, t[k]);                                            \
+        }                                                                                                               \
+        if (accept) {                                                                                                   \
+            closest = t[k];                                                                                             \
+            ref_best = make_ref(REF_QUAD, quad_first + k);                                                              \
+            any = true;                                                                                                 \
+        }                                                                                                               \
     }
     RT_BOX_FACE(0, 0, 1)
     RT_BOX_FACE(1, 2, 1)
@@ -297,7 +319,7 @@ DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
         ph.n[k] += 1ull;                                                  \
     } while (0)
 struct PhaseSums {
-    unsigned long long t[8], l[8], n[8];  // 0 node, 1 leaf, 2 shade, 3 refill; inside the leaf phase: 4 group/instance, 5 medium, 6 primitive
+    unsigned long long t[16], l[16], n[16];  // 0 node, 1 leaf, 2 shade, 3 refill; inside the leaf phase: 4 group/instance, 5 medium, 6 primitive
 };
 #define PH_ARG , PhaseSums &ph
 #define PH_PASS , ph
@@ -413,12 +435,9 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
             }
         }
         break;
-    case GEOM_BOX: {
-        uint32_t face = 0;
-        any = box_closest(sc.quad_aa + o.first, lr, tmin, tmax, closest, face);
-        if (any) ref_best = make_ref(REF_QUAD, o.first + face);
+    case GEOM_BOX:
+        any = box_closest(sc, sc.boxes + o.first, lr, tmin, tmax, closest, ref_best);
         break;
-    }
     case GEOM_QUADS:
         for (uint32_t k = 0; k < o.count; k++) {
             double t;
@@ -447,10 +466,21 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
 
 // Composite leaf: instance chain and, for media, the stochastic volume hit (R/ConstantMedium.h:52-94).
 template <class T>
-DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng)
+DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
 {
+#if RT_PHASES
+    const unsigned long long ph_o0 = __builtin_readcyclecounter();
+#endif
     ObjectRec o = sc.objects[oi];
     Ray lr = to_object_space(sc, o, r);
+#if RT_PHASES
+    {
+        // force the loads to land before the stamp
+        asm volatile("" ::"v"(lr.o.x), "v"(lr.d.z), "v"(o.first));
+        const unsigned long long ph_s0 = ph_o0;
+        PH_SUB_END(8);
+    }
+#endif
     // surfaces: one closest-hit query over [tmin, tmax]; media: two boundary queries (R/ConstantMedium.h:58-64)
     const bool medium = T::MEDIA && o.medium != kNone;
     double t1 = 0.0, t2 = 0.0;
@@ -459,7 +489,11 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
         const double lo = medium ? (pass == 0 ? -DBL_MAX : t1 + 0.0001) : tmin;
         const double hi = medium ? DBL_MAX : tmax;
         double t;
-        if (!geom_closest(sc, o, lr, lo, hi, t, pref)) return false;
+        PH_SUB_BEGIN();
+        const bool got = geom_closest(sc, o, lr, lo, hi, t, pref);
+        asm volatile("" ::"v"(t));
+        PH_SUB_END(o.geom_kind == GEOM_BOX ? 9 : (o.geom_kind == GEOM_BVH ? 10 : 11));
+        if (!got) return false;
         if (pass == 0) t1 = t;
         else t2 = t;
         if (!medium) break;
@@ -498,7 +532,7 @@ DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
     if constexpr (T::COMPOSITE) {
         if ((ref >> kRefShift) == REF_OBJECT) {
             PH_SUB_BEGIN();
-            const bool found = object_test<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
+            const bool found = object_test<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng PH_PASS);
             PH_SUB_END(is_medium_leaf(sc, ref) ? 5 : 4);
             return found;
         }
@@ -1456,7 +1490,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
 #endif
     }
 #if RT_PHASES
-    for (int k = 4; k < 8; k++) {
+    for (int k = 4; k < 16; k++) {
         for (int off = 32; off > 0; off >>= 1) {
             ph.t[k] += __shfl_down(ph.t[k], off, 64);
             ph.l[k] += __shfl_down(ph.l[k], off, 64);
@@ -1467,10 +1501,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         ph.n[k] >>= 10;
     }
     if (lane == 0) {
-        for (int k = 0; k < 8; k++) {
-            atomicAdd(a.ray_counter + 8 + k, ph.t[k]);
-            atomicAdd(a.ray_counter + 16 + k, ph.l[k]);
-            atomicAdd(a.ray_counter + 24 + k, ph.n[k]);
+        for (int k = 0; k < 16; k++) {
+            atomicAdd(a.ray_counter + 16 + k, ph.t[k]);
+            atomicAdd(a.ray_counter + 32 + k, ph.l[k]);
+            atomicAdd(a.ray_counter + 48 + k, ph.n[k]);
         }
         atomicAdd(a.ray_counter + 7, __builtin_readcyclecounter() - ph_start);
     }

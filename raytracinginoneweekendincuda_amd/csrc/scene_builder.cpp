@@ -282,6 +282,42 @@ struct Flattener {
         return make_ref(REF_QUAD, (uint32_t)f.quads.size() - 1);
     }
 
+    // Six consecutive quads that are exactly what MakeBox builds for some corners mn < mx (R/Instance.h:166-184: front,
+    // right, back, left, top, bottom): every face lies in the plane of one corner coordinate, starts at a corner and
+    // spans the rounded extent fl(mx - mn) towards the other one.  Anything else stays a plain list of quads.
+    bool box_of_six(uint32_t first, BoxRec &b) const
+    {
+        static const uint32_t codes[6] = {1 + 3 * 2 + 0, 1 + 3 * 0 + 2, 1 + 3 * 2 + 0, 1 + 3 * 0 + 2, 1 + 3 * 1 + 0, 1 + 3 * 1 + 0};
+        for (int k = 0; k < 6; k++)
+            if (f.quad_aa[first + k].code != codes[k]) return false;
+        const QuadGeom &front = f.quads[first + 0], &back = f.quads[first + 2], &top = f.quads[first + 4];
+        const double mn[3] = {front.qx, front.qy, back.qz}, mx[3] = {back.qx, top.qy, front.qz};
+        for (int k = 0; k < 3; k++)
+            if (!(mn[k] < mx[k]) || !std::isfinite(mn[k]) || !std::isfinite(mx[k])) return false;
+        for (int k = 0; k < 6; k++) {
+            const QuadGeom &g = f.quads[first + k];
+            const double q[3] = {g.qx, g.qy, g.qz}, u[3] = {g.ux, g.uy, g.uz}, v[3] = {g.vx, g.vy, g.vz};
+            const int a = (int)(codes[k] - 1) / 3, p = (int)(codes[k] - 1) % 3, qa = 3 - a - p;
+            if (q[a] != mn[a] && q[a] != mx[a]) return false;
+            const int ax[2] = {p, qa};
+            const double ev[2] = {u[p], v[qa]};
+            for (int e = 0; e < 2; e++) {
+                const double ext = mx[ax[e]] - mn[ax[e]];
+                const bool from_min = q[ax[e]] == mn[ax[e]] && ev[e] == ext;
+                const bool from_max = q[ax[e]] == mx[ax[e]] && ev[e] == -ext;
+                if (!from_min && !from_max) return false;
+            }
+            b.na[k] = f.quad_aa[first + k].na;
+            b.d[k] = f.quad_aa[first + k].d;
+        }
+        for (int k = 0; k < 3; k++) {
+            b.mn[k] = mn[k];
+            b.mx[k] = mx[k];
+        }
+        b.quad_first = first;
+        return true;
+    }
+
     // AAQuad of a quad whose edge vectors each lie along one coordinate axis (code 0 otherwise); see flat_scene.h.
     static AAQuad axis_aligned(const QuadGeom &g)
     {
@@ -408,11 +444,12 @@ struct Flattener {
                 obj.first = first_ref & kRefIndexMask;
                 for (size_t k = 1; k < prims.size(); k++) add_primitive(s.hittables[prims[k] - 1]);
                 if (all_q && prims.size() == 6) {
-                    // MakeBox's faces (R/Instance.h:166-184): front, right, back, left, top, bottom
-                    static const uint32_t box_codes[6] = {1 + 3 * 2 + 0, 1 + 3 * 0 + 2, 1 + 3 * 2 + 0, 1 + 3 * 0 + 2, 1 + 3 * 1 + 0, 1 + 3 * 1 + 0};
-                    bool box = true;
-                    for (int k = 0; k < 6; k++) box &= f.quad_aa[obj.first + k].code == box_codes[k];
-                    if (box) obj.geom_kind = GEOM_BOX;
+                    BoxRec b{};
+                    if (box_of_six(obj.first, b)) {
+                        obj.geom_kind = GEOM_BOX;
+                        obj.first = (uint32_t)f.boxes.size();
+                        f.boxes.push_back(b);
+                    }
                 }
             } else {
                 obj.geom_kind = GEOM_MIXED;

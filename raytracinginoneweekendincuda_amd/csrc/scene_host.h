@@ -63,6 +63,7 @@ struct FlatScene {
     std::vector<SphereAux> msphere_aux;
     std::vector<QuadGeom> quads;
     std::vector<AAQuad> quad_aa;
+    std::vector<BoxRec> boxes;
     std::vector<uint32_t> quad_mat;
     std::vector<ObjectRec> objects;
     std::vector<uint32_t> items;

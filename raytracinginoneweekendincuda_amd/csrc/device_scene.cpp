@@ -304,6 +304,16 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.grid_blocks = 0;
     if (const char *e = std::getenv("RTOW_GRID_BLOCKS")) ra.grid_blocks = std::atoi(e);  // experiments only
     if (ra.grid_blocks > 0) ra.max_blocks_per_cu = 8;
+    // A deep world BVH over composite leaves (scene 9: 400 boxes, two media, an instanced cluster): a leaf phase costs
+    // tens of node steps there, so it pays to wait until most walkers have parked.  A shallow one (Cornell box: 8
+    // leaves) gains nothing from waiting.
+    {
+        const uint32_t world_nodes = s.flat.n_world_nodes;
+        ra.node_burst = world_nodes > 64 ? 12 : 8;
+        ra.park_ratio = world_nodes > 64 ? 4 : 1;
+        if (const char *e = std::getenv("RTOW_BURST")) ra.node_burst = std::atoi(e);  // experiments only
+        if (const char *e = std::getenv("RTOW_PARK")) ra.park_ratio = std::atoi(e);
+    }
     ra.overdue_priority = (p->flags & RT_FLAG_OVERDUE_PRIORITY) ? 1 : 0;
     {
         // Off by default: on the Book-1 scenes a cooperative ray costs ~10x a pixel-parallel one, and every budget

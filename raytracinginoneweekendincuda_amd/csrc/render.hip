@@ -685,6 +685,7 @@ constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenev
 #define RT_ROUNDS 8
 #endif
 constexpr int kBurst = RT_BURST;    // BVH worlds: at most this many node visits between two leaf phases
+
 constexpr int kRounds = RT_ROUNDS;  // node/leaf phase pairs per look at the shading queue
 
 DEV void drain_queue(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
@@ -1390,14 +1391,16 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             // Inner nodes and leaves run in separate phases so that the (long, branchy) leaf tests execute with
             // many lanes at once instead of trailing every node visit with a few.
             for (int round = 0; round < kRounds; round++) {
-                for (int step = 0; step < kBurst; step++) {
+                for (int step = 0; step < (T::COMPOSITE ? a.node_burst : kBurst); step++) {
                     const bool mover = walking && !walk.at_leaves;
 #if RT_SIMPLE_BREAK
                     if (!__any(mover)) break;
 #else
                     const int movers = __popcll(__ballot(mover));
                     const int parked = __popcll(__ballot(walking && walk.at_leaves));
-                    if (movers == 0 || movers < parked) break;  // most walkers are waiting at leaves: go test them
+                    // most walkers are waiting at leaves: go test them.  A composite leaf (box, instance, medium) costs
+                    // tens of node steps, so there the leaf phase waits for a larger share of the walkers.
+                    if (movers == 0 || movers * (T::COMPOSITE ? a.park_ratio : 1) < parked) break;
 #endif
                     {
                         PH_BEGIN();

@@ -485,18 +485,34 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     const bool medium = T::MEDIA && o.medium != kNone;
     double t1 = 0.0, t2 = 0.0;
     uint32_t pref = kNone;
-    for (int pass = 0; pass < 2; pass++) {  // one inlined copy of the geometry query
-        const double lo = medium ? (pass == 0 ? -DBL_MAX : t1 + 0.0001) : tmin;
-        const double hi = medium ? DBL_MAX : tmax;
-        double t;
-        PH_SUB_BEGIN();
-        const bool got = geom_closest(sc, o, lr, lo, hi, t, pref);
-        asm volatile("" ::"v"(t));
-        PH_SUB_END(o.geom_kind == GEOM_BOX ? 9 : (o.geom_kind == GEOM_BVH ? 10 : 11));
-        if (!got) return false;
-        if (pass == 0) t1 = t;
-        else t2 = t;
-        if (!medium) break;
+    if (medium && o.geom_kind == GEOM_SINGLE && (o.first >> kRefShift) == REF_SPHERE) {
+        // The usual boundary: one sphere.  Both queries of R/ConstantMedium.h:58-64 share oc, b, c and the
+        // discriminant (R/Sphere.h:28-34); only the root selection (:36-60) runs twice.
+        const SphereGeom g = sc.spheres[o.first & kRefIndexMask];
+        const Vec oc = lr.o - mk(g.cx, g.cy, g.cz);
+        const double a = dot(lr.d, lr.d);
+        const double b = dot(oc, lr.d);
+        const double c = dot(oc, oc) - g.r2;
+        const double disc = b * b - a * c;
+        if (!(disc > 0.0)) return false;
+        if (!sphere_roots(b, disc, a, -DBL_MAX, DBL_MAX, t1)) return false;
+        if (!sphere_roots(b, disc, a, t1 + 0.0001, DBL_MAX, t2)) return false;
+    } else {
+        for (int pass = 0; pass < 2; pass++) {  // one inlined copy of the geometry query
+            const double lo = medium ? (pass == 0 ? -DBL_MAX : t1 + 0.0001) : tmin;
+            const double hi = medium ? DBL_MAX : tmax;
+            double t;
+            PH_SUB_BEGIN();
+            const bool got = geom_closest(sc, o, lr, lo, hi, t, pref);
+#if RT_PHASES
+            asm volatile("" ::"v"(t));
+#endif
+            PH_SUB_END(o.geom_kind == GEOM_BOX ? 9 : (o.geom_kind == GEOM_BVH ? 10 : 11));
+            if (!got) return false;
+            if (pass == 0) t1 = t;
+            else t2 = t;
+            if (!medium) break;
+        }
     }
     if (!medium) {
         best.t = t1;

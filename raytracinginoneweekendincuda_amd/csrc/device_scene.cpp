@@ -173,6 +173,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_mspheres = (uint32_t)f.mspheres.size();
     d.n_quads = (uint32_t)f.quads.size();
     d.n_objects = (uint32_t)f.objects.size();
+    d.n_boxes = (uint32_t)f.boxes.size();
     d.flags = f.flags;
     s.device[device] = dt;
     return RT_OK;

@@ -16,6 +16,7 @@ enum : uint32_t {
     REF_QUAD = 2u,     // index into quads
     REF_OBJECT = 3u,   // index into objects (instances / boxes / lists / media)
     REF_MEDIUM = 4u,   // only in hit results: index into media
+    REF_BOX = 5u,      // leaves only: index into boxes (a MakeBox box without transform or medium; its hits are REF_QUAD)
     REF_INNER = 14u,   // BVH node marker: children are the next node and the escape target
     REF_NONE = 15u
 };
@@ -123,7 +124,7 @@ struct DeviceScene {
     uint32_t n_world_items;
     uint32_t n_nodes;        // all threaded nodes: the world's first, then sub-BVHs of large groups
     uint32_t n_world_nodes;
-    uint32_t n_spheres, n_mspheres, n_quads, n_objects;
+    uint32_t n_spheres, n_mspheres, n_quads, n_objects, n_boxes;
     uint32_t flags;
 };
 

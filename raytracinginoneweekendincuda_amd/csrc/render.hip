@@ -546,6 +546,19 @@ template <class T>
 DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
 {
     if constexpr (T::COMPOSITE) {
+        if ((ref >> kRefShift) == REF_BOX) {
+            PH_SUB_BEGIN();
+            double t;
+            uint32_t face = kNone;
+            const bool found = box_closest(sc, sc.boxes + (ref & kRefIndexMask), r, tmin, tmax, t, face);
+            if (found) {
+                best.t = t;
+                best.ref = face;
+                best.obj = kNone;
+            }
+            PH_SUB_END(9);
+            return found;
+        }
         if ((ref >> kRefShift) == REF_OBJECT) {
             PH_SUB_BEGIN();
             const bool found = object_test<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng PH_PASS);
@@ -1626,7 +1639,7 @@ hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, K
 
 hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info)
 {
-    const bool composite = sc.n_objects != 0;
+    const bool composite = sc.n_objects != 0 || sc.n_boxes != 0;
     const bool rich = (sc.flags & SCENE_RICH_TEXTURES) != 0;
     if ((sc.flags & SCENE_LIST_ALL_SPHERES) && !rich && sc.n_spheres <= 65535u && !a.force_general)
         return launch_one<TSphereList>(sc, a, stream, info);

@@ -459,6 +459,8 @@ struct Flattener {
                 f.items.insert(f.items.end(), refs.begin(), refs.end());
             }
         }
+        // a plain box needs nothing from the object record: the leaf points at the box itself
+        if (obj.geom_kind == GEOM_BOX && obj.xf_count == 0 && obj.medium == kNone) return make_ref(REF_BOX, obj.first);
         f.objects.push_back(obj);
         return make_ref(REF_OBJECT, (uint32_t)f.objects.size() - 1);
     }

@@ -158,6 +158,8 @@ typedef struct rt_render_params {
 #define RT_FLAG_ACCUMULATE 8u      /* progressive: with KEEP_RNG_STATE, add this launch's samples to the film's running sums;
                                       the pixels then hold sqrt(sum / all samples so far), bit-identical to one launch of that many spp */
 #define RT_FLAG_FORCE_GENERAL 2u   /* tests: run the general kernel even where a specialised instantiation applies */
+#define RT_FLAG_ROW_MAJOR_TILES 16u /* BVH worlds: keep the pixel queue in row-major tile order (default: a short rehearsal ranks
+                                      the 8x8 tiles by rays traced and the heaviest start first; the image is the same either way) */
 
 typedef struct rt_render_stats {
     uint64_t samples;             /* pixels rendered by this rank x spp */

@@ -106,6 +106,8 @@ struct FilmImpl {
     int num_cus = 256;
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
+    uint32_t *tile_cost = nullptr, *tile_order = nullptr;  // per 8x8 tile of this rank's rows: probed rays, and the tiles ranked by them
+    uint32_t n_tiles = 0;
     unsigned long long *host_counters = nullptr;  // pinned mirror of ray_counter, filled by an async copy behind the render
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // begin, after seed, after render, after the counter copy
     bool seeded = false;
@@ -211,6 +213,9 @@ rt_film *rt_film_create(int device, int width, int height, int stripe_rows, int 
         if (e == hipSuccess) f->num_cus = prop.multiProcessorCount;
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking);
+    f->n_tiles = (((uint32_t)width + 7u) >> 3) * (((uint32_t)f->rows_owned + 7u) >> 3);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->tile_cost, (f->n_tiles ? f->n_tiles : 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->tile_order, (f->n_tiles ? f->n_tiles : 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&f->host_counters, kCounterWords * sizeof(unsigned long long), hipHostMallocDefault);
     for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&f->ev[k]);
     if (e != hipSuccess) {
@@ -230,6 +235,8 @@ void rt_film_destroy(rt_film *film)
     if (f->accum) hipFree(f->accum);
     if (f->state) hipFree(f->state);
     if (f->ray_counter) hipFree(f->ray_counter);
+    if (f->tile_cost) hipFree(f->tile_cost);
+    if (f->tile_order) hipFree(f->tile_order);
     if (f->host_counters) hipHostFree(f->host_counters);
     for (int k = 0; k < 4; k++)
         if (f->ev[k]) hipEventDestroy(f->ev[k]);
@@ -336,6 +343,34 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.force_general = (p->flags & RT_FLAG_FORCE_GENERAL) ? 1 : 0;
     const DeviceScene &ds = s.device[f.device]->scene;
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
+    // BVH worlds: heaviest tiles first.  A pixel's samples are one sequential chain, so the frame cannot end before
+    // its longest pixel does (glass: up to max_depth rays per sample).  In row-major order those pixels start
+    // wherever they happen to lie and the frame ends long after the queue has drained (C3: drained at 38 ms, last
+    // wave out at 99 ms).  A rehearsal of the first sample(s) of every pixel -- same RNG streams, nothing written but a
+    // ray count per 8x8 tile -- ranks the tiles; its cost is spp_probe / spp of the frame.  Not for the sphere-list
+    // kernel: there the cooperative scan already finishes a thin tail quickly, and heaviest-first measured slower.
+    {
+        const bool bvh_kernel = f.last_kernel.kind < 8;
+        bool rank_tiles = bvh_kernel && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 && !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
+        if (const char *e = std::getenv("RTOW_TILE_SORT")) rank_tiles = rank_tiles && std::atoi(e) != 0;  // experiments only
+        if (rank_tiles) {
+            int probe_spp = p->samples_per_pixel / 100;
+            probe_spp = probe_spp < 1 ? 1 : (probe_spp > 8 ? 8 : probe_spp);
+            if (const char *e = std::getenv("RTOW_PROBE_SPP")) probe_spp = std::atoi(e);
+            RenderArgs probe = ra;
+            probe.probe = 1;
+            probe.spp = probe_spp;
+            probe.accum = nullptr;
+            probe.spp_before = 0;
+            probe.tile_cost = f.tile_cost;
+            probe.tile_order = nullptr;
+            HIP_TRY(hipMemsetAsync(f.tile_cost, 0, f.n_tiles * sizeof(uint32_t), stream));
+            HIP_TRY(p->variant ? launch_render_fast(ds, probe, stream) : launch_render_strict(ds, probe, stream));
+            HIP_TRY(launch_tile_order(f.tile_cost, f.tile_order, f.n_tiles, stream));
+            HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, queue cursor
+            ra.tile_order = f.tile_order;
+        }
+    }
     HIP_TRY(p->variant ? launch_render_fast(ds, ra, stream) : launch_render_strict(ds, ra, stream));
     HIP_TRY(hipEventRecord(f.ev[2], stream));
     // The counters come home on the film's own stream: a blocking hipMemcpy in rt_render_finish would wait for every

@@ -704,6 +704,12 @@ constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenev
 #ifndef RT_SIMPLE_BREAK
 #define RT_SIMPLE_BREAK 0
 #endif
+#ifndef RT_PROBE_ON
+#define RT_PROBE_ON 1
+#endif
+#ifndef RT_ORDER_ON
+#define RT_ORDER_ON 1
+#endif
 #ifndef RT_STAMP
 #define RT_STAMP 0  // diagnostic build: wall-clock stamps of queue exhaustion / first and last wave exit
 #endif
@@ -1310,6 +1316,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     uint32_t nrays = 0;
 
     uint32_t pix_rays = 0;  // rays this lane's current pixel has traced so far
+    uint32_t my_tile = 0;   // tile of the current pixel (cost probe)
     int boost_left = 0;     // extra overdue-only passes still allowed before the next pixel-parallel pass
     // BVH worlds: per-lane resumable traversal (see Walk) and the hit it has found so far
     Walk walk{};
@@ -1360,7 +1367,9 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
 #endif
                 const uint32_t slot = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (!active && slot < total_slots) {
-                    const uint32_t tile = slot >> 6, w = slot & 63u;
+                    // heaviest tiles first when the launcher has ranked them (see rt_render_launch); else row-major
+                    const uint32_t w = slot & 63u;
+                    const uint32_t tile = (RT_ORDER_ON && a.tile_order) ? a.tile_order[slot >> 6] : slot >> 6;
                     const int pi = (int)((tile % tiles_x) * 8u + (w & 7u));
                     const int lr = (int)((tile / tiles_x) * 8u + (w >> 3));
                     if (pi < a.width && lr < a.rows_owned) {
@@ -1381,6 +1390,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         sample = 0;
                         depth = 0;
                         pix_rays = 0;
+                        if (RT_PROBE_ON) my_tile = tile;
                         ray = camera_ray(cam, i, j, a.width, a.height, rng);
                         active = true;
                         if constexpr (T::WORLD == 0) {
@@ -1486,6 +1496,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                     throughput = mk(1.0, 1.0, 1.0);
                     accumulated = mk(0.0, 0.0, 0.0);
                     depth = 0;
+                } else if (RT_PROBE_ON && a.probe) {
+                    // cost probe: the samples were a rehearsal (the saved RNG state is untouched); book the rays
+                    atomicAdd(a.tile_cost + my_tile, pix_rays);
+                    active = false;
                 } else {
                     // R/kernel.cu:146-153: save the RNG state, average, gamma 2
                     a.state[0 * (size_t)a.n_pixels + local] = rng.d;
@@ -1555,6 +1569,58 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
 }
 
 #if RT_STRICT
+// Rank the tiles by probed cost, heaviest first.  A pixel's samples are sequential (one RNG stream), so the frame can
+// never end before its longest pixel does: those pixels have to start first, not wherever row-major order puts them.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, uint32_t *order, uint32_t n)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t peak;
+    __shared__ unsigned long long total;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        peak = 1;
+        total = 0;
+    }
+    __syncthreads();
+    uint32_t mx = 0;
+    unsigned long long sum = 0;
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+        mx = cost[k] > mx ? cost[k] : mx;
+        sum += cost[k];
+    }
+    atomicMax(&peak, mx);
+    atomicAdd(&total, sum);
+    __syncthreads();
+    const uint32_t top = peak;
+    // Nothing to gain where no tile stands out (Cornell box: every path is short): keep the row-major order.
+    if ((unsigned long long)top * n <= 4ull * total) {
+        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) order[k] = k;
+        return;
+    }
+    auto klass = [top](uint32_t c) { return 255u - (uint32_t)(((unsigned long long)c * 255ull) / top); };  // 0 = heaviest
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) atomicAdd(&hist[klass(cost[k])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 256; b++) {
+            uint32_t c = hist[b];
+            hist[b] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) order[atomicAdd(&hist[klass(cost[k])], 1u)] = k;
+}
+
+hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, hipStream_t stream)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, tile_order, n_tiles);
+    return hipGetLastError();
+}
+#endif
+
+#if RT_STRICT
 #define RT_SUFFIX strict
 #else
 #define RT_SUFFIX fast
@@ -1582,9 +1648,12 @@ using TBvhPrims = Traits<0, false, false, RT_WAVES_BVH>;
 #ifndef RT_WAVES_GENERAL
 #define RT_WAVES_GENERAL 2
 #endif
+#ifndef RT_WAVES_INSTANCES
+#define RT_WAVES_INSTANCES 3  // 168 VGPRs: the instances kernel sits right at the step from three waves per SIMD to two
+#endif
 using TBvhGeneral = Traits<0, true, true, RT_WAVES_GENERAL>;
 using TListGeneral = Traits<1, true, true, RT_WAVES_GENERAL>;
-using TBvhInstances = Traits<0, true, false, RT_WAVES_GENERAL, false>;  // instances / boxes, no media, plain textures (C4)
+using TBvhInstances = Traits<0, true, false, RT_WAVES_INSTANCES, false>;  // instances / boxes, no media, plain textures (C4)
 using TBvhMedia = Traits<0, true, false, RT_WAVES_GENERAL, true>;       // + ConstantMedium (Cornell smoke)
 
 template <class T>

@@ -13,6 +13,9 @@ struct SeedArgs {
     uint32_t *state;             // 6 planes of n_pixels words: d, v0..v4
     const uint32_t *jump_table;  // kJumpTableWords
     Xorwow base;                 // salted seed state (sequence 0)
+    uint32_t *tile_cost;        // probe launches: rays traced per 8x8 tile (one counter per tile of this rank's rows)
+    const uint32_t *tile_order; // render launches: queue position -> tile (nullptr = tiles in row-major order)
+    int32_t probe;              // 1 = cost probe: trace `spp` samples per pixel, write nothing but tile_cost
     uint32_t n_pixels;
     int32_t width, stripe_rows, rank, world_size;
 };
@@ -24,6 +27,9 @@ struct RenderArgs {
     uint32_t *state;
     unsigned long long *ray_counter;
     uint32_t *cursor;            // pixel-queue cursor, zeroed before every launch
+    uint32_t *tile_cost;        // probe launches: rays traced per 8x8 tile (one counter per tile of this rank's rows)
+    const uint32_t *tile_order; // render launches: queue position -> tile (nullptr = tiles in row-major order)
+    int32_t probe;              // 1 = cost probe: trace `spp` samples per pixel, write nothing but tile_cost
     uint32_t n_pixels;
     int32_t width, height, rows_owned;
     int32_t spp, max_depth;
@@ -53,5 +59,8 @@ hipError_t launch_render_strict(const DeviceScene &sc, const RenderArgs &a, hipS
 hipError_t launch_render_fast(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream);
 hipError_t kernel_info_strict(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info);
 hipError_t kernel_info_fast(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info);
+
+// tile_order[k] = the tile with the k-th highest cost (counting sort over 256 cost classes; one workgroup)
+hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, hipStream_t stream);
 
 } // namespace rtow

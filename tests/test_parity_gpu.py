@@ -128,6 +128,19 @@ def test_frames_in_flight_on_separate_films_are_independent():
         assert st.rays == st_alone.rays, sid
 
 
+@pytest.mark.parametrize("scene_id", [0, 9])
+def test_tile_ranking_does_not_change_the_image(scene_id, earth):
+    """BVH worlds rehearse the first sample of every pixel, rank the 8x8 tiles by rays traced and start the heaviest
+    first (the frame cannot end before its longest pixel).  The rehearsal writes nothing but tile costs -- the saved RNG
+    streams are untouched -- so the frame equals the row-major one bit for bit; RT_FLAG_ROW_MAJOR_TILES (16) turns it off."""
+    w = h = 256                                     # 1024 tiles: the smallest frame that is ranked
+    s = rt.builtin_scene(scene_id, 0, w, h, earth=earth if scene_id == 9 else None)
+    ranked, st_ranked = s.render(w, h, 32, variant=0)
+    plain, st_plain = s.render(w, h, 32, variant=0, flags=16)
+    assert np.array_equal(ranked.view(np.uint64), plain.view(np.uint64))
+    assert st_ranked.rays == st_plain.rays          # the rehearsal's rays are not counted
+
+
 def test_full_size_rows_match_oracle(oracle):
     """Config C2 geometry (1200x800, list world): pixel RNG sequences depend on the full width, so check
     real rows of the full-size frame at low spp against the oracle."""

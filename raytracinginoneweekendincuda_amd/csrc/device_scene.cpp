@@ -303,7 +303,9 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.state = f.state;
     ra.ray_counter = f.ray_counter;
     ra.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 1);
-    ra.coop_threshold = p->coop_threshold > 0 ? p->coop_threshold : 16;
+    ra.coop_threshold = p->coop_threshold > 0 ? p->coop_threshold : 24;
+    ra.coop_single = 0;
+    if (const char *e = std::getenv("RTOW_COOP_SINGLE")) ra.coop_single = std::atoi(e);  // experiments only
     ra.num_cus = f.num_cus;
     ra.shade_batch = p->shade_batch > 0 ? p->shade_batch : 16;
     ra.max_blocks_per_cu = p->max_blocks_per_cu;

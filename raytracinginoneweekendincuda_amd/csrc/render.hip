@@ -938,6 +938,94 @@ DEV void scan_cooperative(const SphereView &sv, uint32_t lane, unsigned long lon
     }
 }
 
+// Lane exchange through the LDS crossbar (ds_bpermute: no memory traffic).
+DEV int lane_read(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+DEV double lane_read(double x, int src_lane)
+{
+    int lo = lane_read(__double2loint(x), src_lane);
+    int hi = lane_read(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
+}
+DEV void min_with_lane(double &t, uint32_t &k, int partner)
+{
+    double ot = lane_read(t, partner);
+    uint32_t ok = (uint32_t)lane_read((int)k, partner);
+    bool take = (ot < t) || (ot == t && ok < k);
+    t = take ? ot : t;
+    k = take ? ok : k;
+}
+
+// Ray-cooperative scan for a thin wave, several rays at a time: the L live rays are dealt to L groups of g = 64 / m
+// lanes (m = L rounded up to a power of two), lane s of a group tests spheres s, s+g, s+2g, ...; one reduction over
+// (t, index) per group serves all the rays at once.  Same winner as scan_cooperative (and as the sequential scan),
+// at 1/L of its per-ray bookkeeping; against the pixel-parallel scan every lane does 1/g of the sphere tests.
+DEV void scan_grouped(const SphereView &sv, uint32_t lane, unsigned long long todo, const Ray &ray, double tmin, double tmax,
+                      HitInfo &best, bool &hit)
+{
+    const int L = __popcll(todo);
+    int log2m = 0;
+    while ((1 << log2m) < L) log2m++;
+    const int log2g = 6 - log2m;
+    const uint32_t g = 1u << log2g;
+    const uint32_t q = lane >> log2g, s = lane & (g - 1u);  // my ray slot and my place in its group
+    // owner of slot q = the q-th live lane
+    int owner = (int)lane;
+    {
+        unsigned long long m = todo;
+        for (int r = 0; r < L; r++) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            owner = q == (uint32_t)r ? src : owner;
+        }
+    }
+    Ray r;
+    r.o = mk(lane_read(ray.o.x, owner), lane_read(ray.o.y, owner), lane_read(ray.o.z, owner));
+    r.d = mk(lane_read(ray.d.x, owner), lane_read(ray.d.y, owner), lane_read(ray.d.z, owner));
+    const double a = dot(r.d, r.d);
+    double bt = tmax;
+    uint32_t bk = kNone;
+    for (uint32_t base = 0; base < sv.n_padded; base += 4u * g) {
+        double b[4], c[4], disc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t k = base + g * u + s;
+            k = k < sv.n_padded ? k : sv.n_padded - 1u;  // keeps the address inside the planes
+            Vec oc = r.o - mk(sv.cx[k], sv.cy[k], sv.cz[k]);
+            b[u] = dot(oc, r.d);
+            c[u] = dot(oc, oc) - sv.r2[k];
+            disc[u] = b[u] * b[u] - a * c[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t k = base + g * u + s;
+            if (k < sv.n && disc[u] > 0.0 && !(b[u] > 0.0 && c[u] > 0.0)) {
+                double t;
+                if (sphere_roots(b[u], disc[u], a, tmin, bt, t)) {
+                    bt = t;
+                    bk = k;
+                }
+            }
+        }
+    }
+    // minimum over the group: partners at distance 1, 2 (quad permutes), 4 (half-row mirror), 8 (row mirror), then 16, 32
+    if (log2g >= 1) min_step<0xB1, 0xf>(bt, bk);   // quad_perm [1,0,3,2]
+    if (log2g >= 2) min_step<0x4E, 0xf>(bt, bk);   // quad_perm [2,3,0,1]
+    if (log2g >= 3) min_step<0x141, 0xf>(bt, bk);  // row_half_mirror
+    if (log2g >= 4) min_step<0x140, 0xf>(bt, bk);  // row_mirror
+    if (log2g >= 5) min_with_lane(bt, bk, (int)lane ^ 16);
+    if (log2g >= 6) min_with_lane(bt, bk, (int)lane ^ 32);
+    // back to the owners: live lane number r reads the first lane of group r
+    const int rank = __popcll(todo & ((1ull << lane) - 1ull));
+    const double rt = lane_read(bt, rank << log2g);
+    const uint32_t rk = (uint32_t)lane_read((int)bk, rank << log2g);
+    if ((todo >> lane) & 1ull) {
+        hit = rk != kNone;
+        best.t = rt;
+        best.ref = make_ref(REF_SPHERE, rk);
+        best.obj = kNone;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // hit record, built once per bounce from (t, primitive)
 // ------------------------------------------------------------------------------------------------
@@ -1420,7 +1508,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             if (!boost && __popcll(live) >= a.coop_threshold) {
                 if (active) hit = scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h);
             } else {
-                scan_cooperative(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
+                if (sv.in_lds && !a.coop_single) scan_grouped(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
+                else scan_cooperative(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
             }
         }
         if constexpr (T::WORLD == 0) {

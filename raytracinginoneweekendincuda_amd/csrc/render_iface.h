@@ -39,6 +39,7 @@ struct RenderArgs {
     int32_t lds_nodes;      // set by the launcher: BVH nodes are staged in LDS
     int32_t force_general;  // tests: use the general kernel even where a specialised one applies
     int32_t coop_threshold; // sphere-list kernel: below this many live lanes a wave scans cooperatively
+    int32_t coop_single;    // experiments: cooperative scan one ray at a time (the older scheme) instead of in groups
     int32_t num_cus;
     int32_t lds_spheres;    // set by the launcher: sphere planes staged in LDS for the cooperative scan
     int32_t overdue_priority;

@@ -8,6 +8,7 @@
 // to what the reference's constructors compute.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -256,6 +257,7 @@ struct Flattener {
     // zero displacement (centre(t) = c0 + frac * 0 = c0 exactly), so that a wave's leaf tests run one code path
     // instead of two.  Not done if a centre component is -0.0 (c0 + 0.0 would flip it to +0.0).
     bool unify_spheres = false;
+    const bool plain_quads = std::getenv("RTOW_PLAIN_QUADS") != nullptr && std::atoi(std::getenv("RTOW_PLAIN_QUADS")) != 0;
 
     uint32_t add_primitive(const HostHittable &h, bool world_leaf = false)
     {
@@ -277,7 +279,8 @@ struct Flattener {
         }
         f.quads.push_back({h.q.x, h.q.y, h.q.z, h.u.x, h.u.y, h.u.z, h.v.x, h.v.y, h.v.z, h.w.x, h.w.y, h.w.z,
                            h.normal.x, h.normal.y, h.normal.z, h.plane_d});
-        f.quad_aa.push_back(axis_aligned(f.quads.back()));
+        // RTOW_PLAIN_QUADS=1 (tests): every quad takes the general test, boxes stay lists of six quads
+        f.quad_aa.push_back(plain_quads ? AAQuad{} : axis_aligned(f.quads.back()));
         f.quad_mat.push_back(h.material - 1);
         return make_ref(REF_QUAD, (uint32_t)f.quads.size() - 1);
     }

@@ -116,6 +116,32 @@ def test_make_box_faces_and_boxes():
     assert abs((bb[0] - rb[0]) - 265) < 1e-9 and abs((bb[4] - rb[4]) - 295) < 1e-9
 
 
+def test_boxes_are_recognised_and_everything_else_stays_a_quad_list():
+    """Lowering of MakeBox (R/Instance.h:166-184): a plain box becomes a leaf of its own (REF_BOX, no object record), an
+    instanced box keeps its object record; six quads that are not a box (one face moved) stay a list of quads."""
+    def objects(build):
+        s = rt.Scene()
+        m = s.Lambertian((0.5, 0.5, 0.5))
+        items = build(s, m) + [s.Sphere((0, -1000, 0), 999.0, m)]
+        s.SetWorld(s.BvhNode(items))
+        s.Camera((0, 1, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0)
+        s.Commit()
+        return s.info()["n_objects"], s.info()["n_quads"]
+
+    assert objects(lambda s, m: [s.MakeBox((0, 0, 0), (1, 2, 3), m)]) == (0, 6)
+    assert objects(lambda s, m: [s.Translate(s.MakeBox((0, 0, 0), (1, 2, 3), m), (1, 0, 0))]) == (1, 6)
+
+    def not_a_box(s, m):     # MakeBox's six faces, the top one lifted off the others
+        mn, mx = (0.0, 0.0, 0.0), (1.0, 2.0, 3.0)
+        dx, dy, dz = (1.0, 0, 0), (0, 2.0, 0), (0, 0, 3.0)
+        neg = lambda v: tuple(-c for c in v)
+        faces = [((mn[0], mn[1], mx[2]), dx, dy), ((mx[0], mn[1], mx[2]), neg(dz), dy), ((mx[0], mn[1], mn[2]), neg(dx), dy),
+                 ((mn[0], mn[1], mn[2]), dz, dy), ((mn[0], mx[1] + 0.5, mx[2]), dx, neg(dz)), ((mn[0], mn[1], mn[2]), dx, dz)]
+        return [s.HittableList([s.Quad(q, u, v, m) for q, u, v in faces])]
+
+    assert objects(not_a_box) == (1, 6)
+
+
 def test_stripe_rows_and_deinterleave():
     H, W = 50, 7
     for world in (1, 2, 3, 8):

@@ -141,6 +141,62 @@ def test_tile_ranking_does_not_change_the_image(scene_id, earth):
     assert st_ranked.rays == st_plain.rays          # the rehearsal's rays are not counted
 
 
+def _quad_zoo(world_kind, plain):
+    """Quads in every axis pairing and winding, a slanted quad, boxes plain / instanced / paper-thin / far from the origin."""
+    import os
+    os.environ["RTOW_PLAIN_QUADS"] = "1" if plain else "0"
+    try:
+        s = rt.Scene()
+        red, green, grey = s.Lambertian((0.65, 0.05, 0.05)), s.Lambertian((0.12, 0.45, 0.15)), s.Lambertian((0.73, 0.73, 0.73))
+        metal, glass, light = s.Metal((0.8, 0.8, 0.9), 0.1), s.Dielectric(1.5), s.DiffuseLight((4.0, 4.0, 4.0))
+        items = []
+        e = [(1.5, 0, 0), (0, 1.5, 0), (0, 0, 1.5)]
+        k = 0
+        for a in range(3):                       # normal axis
+            for p in range(3):                   # u axis, v on the remaining one: all six (a, p) pairings
+                if p == a:
+                    continue
+                q = 3 - a - p
+                for su, sv in ((1, 1), (-1, 1), (1, -1)):
+                    u = tuple(su * c for c in e[p])
+                    v = tuple(sv * c for c in e[q])
+                    org = [-6.0 + 1.7 * (k % 7), -2.0 + 1.9 * (k // 7), -3.0 - 0.3 * k]
+                    items.append(s.Quad(org, u, v, (red, green, grey, metal)[k % 4]))
+                    k += 1
+        items.append(s.Quad((-1.0, 3.5, -4.0), (2.0, 0.3, 0.1), (0.2, 1.5, -0.4), green))          # not axis-aligned
+        items.append(s.Quad((-8.0, 6.0, -12.0), (16.0, 0, 0), (0, 0, 14.0), light))
+        items.append(s.MakeBox((-5.0, -3.0, -2.0), (-3.5, -1.0, -0.5), grey))                      # plain box leaf
+        items.append(s.MakeBox((1000.0, -3.0, -2.0), (1001.5, -1.0, -0.5), red))                   # far from the origin
+        items.append(s.MakeBox((0.0, -3.0, -2.0), (1.5, -3.0 + 1e-9, -0.5), green))                # paper-thin
+        items.append(s.Translate(s.RotateY(s.MakeBox((0, 0, 0), (1.6, 2.8, 1.6), glass), 18.0), (2.5, -3.0, -3.0)))
+        items.append(s.Translate(s.RotateY(s.MakeBox((0, 0, 0), (1.2, 1.2, 1.2), metal), -25.0), (-1.5, -3.0, -1.0)))
+        items.append(s.Sphere((0.0, -1003.0, 0.0), 1000.0, grey))
+        world = s.BvhNode(items) if world_kind == 0 else s.HittableList(items)
+        s.SetWorld(world)
+        s.Camera((0.5, 1.0, 9.0), (0.0, 0.0, -2.0), (0, 1, 0), 55.0, 96 / 64, 0.0, 10.0, 0.0, 1.0, (0.1, 0.1, 0.15))
+        s.Commit()
+        return s
+    finally:
+        os.environ.pop("RTOW_PLAIN_QUADS", None)
+
+
+@pytest.mark.parametrize("world_kind", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_axis_aligned_quads_and_boxes_equal_the_general_quad_test(world_kind, variant):
+    """flat_scene.h AAQuad / BoxRec: the one-multiply plane and interior tests, the six-planes-at-once box test and its
+    inside / outside classification of the hit point give the same frame, bit for bit, as R/Quad.h:52-99 evaluated in
+    full for every quad (RTOW_PLAIN_QUADS=1 at commit time).  Both builds: the shortcut drops exact zeros only."""
+    fast = _quad_zoo(world_kind, plain=False)
+    full = _quad_zoo(world_kind, plain=True)
+    assert fast.info()["n_quads"] == full.info()["n_quads"]
+    assert fast.info()["n_objects"] == 2 and full.info()["n_objects"] == 5   # plain boxes are leaves of their own (REF_BOX)
+    a, sa = fast.render(96, 64, 8, variant=variant)
+    b, sb = full.render(96, 64, 8, variant=variant)
+    assert sa.rays == sb.rays
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    assert np.isfinite(a).all() and a.max() > 0.2
+
+
 def test_full_size_rows_match_oracle(oracle):
     """Config C2 geometry (1200x800, list world): pixel RNG sequences depend on the full width, so check
     real rows of the full-size frame at low spp against the oracle."""

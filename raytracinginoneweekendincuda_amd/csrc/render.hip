@@ -664,6 +664,33 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
     // tmax = its own t changes nothing; a medium draws again, so only media are re-tested.
     bool again = nb != na;
     if constexpr (T::MEDIA) again = again || is_medium_leaf(sc, nb);
+    if constexpr (!T::COMPOSITE) {
+        // The common bottom node of a sphere world: two moving-sphere rows (static spheres are stored as such rows too,
+        // see unify_spheres).  Both rows are fetched together -- one round trip to L2 instead of two -- and tested in
+        // the reference's order.
+        if ((na >> kRefShift) == REF_MSPHERE && (nb >> kRefShift) == REF_MSPHERE) {
+            const bool unit_time = (sc.flags & SCENE_MS_UNIT_TIME) != 0;
+            const MSphereGeom ga = sc.mspheres[na & kRefIndexMask], gb = sc.mspheres[nb & kRefIndexMask];
+            double t;
+            if (sphere_test(r.o - msphere_center(ga, r.tm, unit_time), r.d, w.a, ga.r2, tmin, w.closest, t)) {
+                w.any = true;
+                w.closest = t;
+                best.t = t;
+                best.ref = na;
+                best.obj = kNone;
+            }
+            if (again && sphere_test(r.o - msphere_center(gb, r.tm, unit_time), r.d, w.a, gb.r2, tmin, w.closest, t)) {
+                w.any = true;
+                w.closest = t;
+                best.t = t;
+                best.ref = nb;
+                best.obj = kNone;
+            }
+            w.node = next;
+            w.at_leaves = false;
+            return;
+        }
+    }
     for (int c = 0; c < 2; c++) {  // one inlined copy of the leaf test
         if (c == 1 && !again) break;
         if (leaf_test<T>(sc, c ? nb : na, r, w.a, tmin, w.closest, best, rng PH_PASS)) {

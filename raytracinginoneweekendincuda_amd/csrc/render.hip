@@ -1562,6 +1562,15 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         if (mover) {
                             walk_node(nv, ray, 0.001, walk);
                             walking = walk.node != kNone;
+                            // Primitive worlds (deep BVH, cheap leaves): a second visit before the next look at the
+                            // wave's state -- the ballots and counts that steer the phases cost a fifth of a node visit.
+                            // Not for composite worlds: the Cornell box's tree is three levels deep (measured -17 %).
+                            if constexpr (!T::COMPOSITE) {
+                                if (walking && !walk.at_leaves) {
+                                    walk_node(nv, ray, 0.001, walk);
+                                    walking = walk.node != kNone;
+                                }
+                            }
                         }
                         PH_END(0, mover);
                     }

@@ -408,8 +408,12 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         }
         if (std::getenv("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;
-            static const char *name[12] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
+            const char *name[12] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
                                            "    record+xforms", "    box", "    sub-BVH", "    other geometry"};
+            if (f.last_kernel.kind >= 16) {  // sphere-list kernel: slots 0 / 1 are its two scans
+                name[0] = "scan, pixel-parallel";
+                name[1] = "scan, cooperative";
+            }
             const double total = (double)c[7];
             for (int k = 0; k < 12; k++)
                 if (k != 7)

@@ -1533,10 +1533,14 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         if constexpr (T::WORLD == 2) {
             if (boost) todo = overdue;
             if (!boost && __popcll(live) >= a.coop_threshold) {
+                PH_BEGIN();
                 if (active) hit = scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h);
+                PH_END(0, active);
             } else {
+                PH_BEGIN();
                 if (sv.in_lds && !a.coop_single) scan_grouped(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
                 else scan_cooperative(sv, lane, todo, ray, 0.001, DBL_MAX, h, hit);
+                PH_END(1, (todo >> lane) & 1ull);
             }
         }
         if constexpr (T::WORLD == 0) {

@@ -176,6 +176,8 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_quads = (uint32_t)f.quads.size();
     d.n_objects = (uint32_t)f.objects.size();
     d.n_boxes = (uint32_t)f.boxes.size();
+    d.n_xforms = (uint32_t)f.xforms.size();
+    d.lds_quad_aa = d.lds_boxes = d.lds_objects = d.lds_xforms = kNone;
     d.flags = f.flags;
     s.device[device] = dt;
     return RT_OK;

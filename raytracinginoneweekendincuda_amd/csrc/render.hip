@@ -87,6 +87,17 @@ DEV uint32_t lds_node_u32(uint32_t n_nodes, uint32_t plane, uint32_t node)
     return reinterpret_cast<const uint32_t *>(lds_raw + (size_t)6 * n_nodes * sizeof(double))[plane * n_nodes + node];
 }
 
+// Small tables staged in LDS (DeviceScene::lds_*): a row by byte offset off the same symbol.
+template <class R>
+DEV R lds_row(uint32_t byte_off, uint32_t idx)
+{
+    return *reinterpret_cast<const R *>(lds_raw + byte_off + idx * (uint32_t)sizeof(R));
+}
+DEV AAQuad get_quad_aa(const DeviceScene &sc, uint32_t i) { return sc.lds_quad_aa != kNone ? lds_row<AAQuad>(sc.lds_quad_aa, i) : sc.quad_aa[i]; }
+DEV BoxRec get_box(const DeviceScene &sc, uint32_t i) { return sc.lds_boxes != kNone ? lds_row<BoxRec>(sc.lds_boxes, i) : sc.boxes[i]; }
+DEV ObjectRec get_object(const DeviceScene &sc, uint32_t i) { return sc.lds_objects != kNone ? lds_row<ObjectRec>(sc.lds_objects, i) : sc.objects[i]; }
+DEV Xform get_xform(const DeviceScene &sc, uint32_t i) { return sc.lds_xforms != kNone ? lds_row<Xform>(sc.lds_xforms, i) : sc.xforms[i]; }
+
 // Scene tables are immutable for the whole launch.  Reading them through the constant address space tells
 // the compiler so: a wave-uniform row then always comes through the scalar cache into SGPRs, even though the
 // kernel stores pixels inside its main loop (which defeats alias analysis for ordinary global loads).
@@ -215,7 +226,7 @@ DEV bool aa_quad_test(const AAQuad &q, const Ray &r, double tmin, double tmax, d
 }
 DEV bool quad_test_at(const DeviceScene &sc, uint32_t idx, const Ray &r, double tmin, double tmax, double &t)
 {
-    const AAQuad q = sc.quad_aa[idx];
+    const AAQuad q = get_quad_aa(sc, idx);
     switch (q.code) {
     case 1 + 3 * 0 + 1: return aa_quad_test<0, 1>(q, r, tmin, tmax, t);
     case 1 + 3 * 0 + 2: return aa_quad_test<0, 2>(q, r, tmin, tmax, t);
@@ -238,22 +249,22 @@ DEV bool quad_test_at(const DeviceScene &sc, uint32_t idx, const Ray &r, double 
 //   mn[p] + m <= P[p] <= mx[p] - m  =>  2^-30 <= (P[p] - Q[p]) / u[p] <= 1 - 2^-31  =>  alpha in [0, 1] for certain;
 //   P[p] < mn[p] - m or P[p] > mx[p] + m  =>  alpha < 0 or alpha > 1 for certain;
 // the same for beta along q.  Only a hit point inside the 2m sliver around an edge needs alpha / beta themselves.
-DEV bool box_closest(const DeviceScene &sc, const BoxRec *b, const Ray &r, double tmin, double tmax, double &t_best,
+DEV bool box_closest(const DeviceScene &sc, const BoxRec &bx, const Ray &r, double tmin, double tmax, double &t_best,
                      uint32_t &ref_best)
 {
     double t[6];
     bool ok[6];
-    ok[0] = aa_plane<2>(b->na[0], b->d[0], r, tmin, tmax, t[0]);  // front
-    ok[1] = aa_plane<0>(b->na[1], b->d[1], r, tmin, tmax, t[1]);  // right
-    ok[2] = aa_plane<2>(b->na[2], b->d[2], r, tmin, tmax, t[2]);  // back
-    ok[3] = aa_plane<0>(b->na[3], b->d[3], r, tmin, tmax, t[3]);  // left
-    ok[4] = aa_plane<1>(b->na[4], b->d[4], r, tmin, tmax, t[4]);  // top
-    ok[5] = aa_plane<1>(b->na[5], b->d[5], r, tmin, tmax, t[5]);  // bottom
-    const Vec mn = mk(b->mn[0], b->mn[1], b->mn[2]), mx = mk(b->mx[0], b->mx[1], b->mx[2]);
+    ok[0] = aa_plane<2>(bx.na[0], bx.d[0], r, tmin, tmax, t[0]);  // front
+    ok[1] = aa_plane<0>(bx.na[1], bx.d[1], r, tmin, tmax, t[1]);  // right
+    ok[2] = aa_plane<2>(bx.na[2], bx.d[2], r, tmin, tmax, t[2]);  // back
+    ok[3] = aa_plane<0>(bx.na[3], bx.d[3], r, tmin, tmax, t[3]);  // left
+    ok[4] = aa_plane<1>(bx.na[4], bx.d[4], r, tmin, tmax, t[4]);  // top
+    ok[5] = aa_plane<1>(bx.na[5], bx.d[5], r, tmin, tmax, t[5]);  // bottom
+    const Vec mn = mk(bx.mn[0], bx.mn[1], bx.mn[2]), mx = mk(bx.mx[0], bx.mx[1], bx.mx[2]);
     const double k30 = 9.313225746154785e-10;  // 2^-30
     const Vec m = mk(k30 * (fabs(mn.x) + fabs(mx.x)), k30 * (fabs(mn.y) + fabs(mx.y)), k30 * (fabs(mn.z) + fabs(mx.z)));
     const Vec in_lo = mn + m, in_hi = mx - m, out_lo = mn - m, out_hi = mx + m;
-    const uint32_t quad_first = b->quad_first;
+    const uint32_t quad_first = bx.quad_first;
     double closest = tmax;
     bool any = false;
 #define RT_BOX_FACE(k, P, Q)                                                                                            \
@@ -262,7 +273,7 @@ DEV bool box_closest(const DeviceScene &sc, const BoxRec *b, const Ray &r, doubl
         bool accept = pp >= comp<P>(in_lo) && pp <= comp<P>(in_hi) && pq >= comp<Q>(in_lo) && pq <= comp<Q>(in_hi);     \
         const bool outside = pp < comp<P>(out_lo) || pp > comp<P>(out_hi) || pq < comp<Q>(out_lo) || pq > comp<Q>(out_hi); \
         if (!accept && !outside) {                                                                                      \
-            const AAQuad f = sc.quad_aa[quad_first + k];                                                                \
+            const AAQuad f = get_quad_aa(sc, quad_first + k);                                                              \
             accept = aa_inside<P, Q>(f.wa, f.qp, f.qq, f.ku, f.kv, r, t[k]);                                            \
         }                                                                                                               \
         if (accept) {                                                                                                   \
@@ -346,7 +357,7 @@ DEV Ray to_object_space(const DeviceScene &sc, const ObjectRec &o, const Ray &r)
 {
     Ray lr = r;
     for (uint32_t k = 0; k < o.xf_count; k++) {
-        Xform x = sc.xforms[o.xf_first + k];
+        Xform x = get_xform(sc, o.xf_first + k);
         if (x.kind == XF_TRANSLATE) {
             lr.o = lr.o - mk(x.a, x.b, x.c);
         } else {
@@ -436,7 +447,7 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
         }
         break;
     case GEOM_BOX:
-        any = box_closest(sc, sc.boxes + o.first, lr, tmin, tmax, closest, ref_best);
+        any = box_closest(sc, get_box(sc, o.first), lr, tmin, tmax, closest, ref_best);
         break;
     case GEOM_QUADS:
         for (uint32_t k = 0; k < o.count; k++) {
@@ -471,7 +482,7 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
 #if RT_PHASES
     const unsigned long long ph_o0 = __builtin_readcyclecounter();
 #endif
-    ObjectRec o = sc.objects[oi];
+    ObjectRec o = get_object(sc, oi);
     Ray lr = to_object_space(sc, o, r);
 #if RT_PHASES
     {
@@ -539,7 +550,7 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
 
 DEV bool is_medium_leaf(const DeviceScene &sc, uint32_t ref)
 {
-    return (ref >> kRefShift) == REF_OBJECT && sc.objects[ref & kRefIndexMask].medium != kNone;
+    return (ref >> kRefShift) == REF_OBJECT && get_object(sc, ref & kRefIndexMask).medium != kNone;
 }
 
 template <class T>
@@ -550,7 +561,7 @@ DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
             PH_SUB_BEGIN();
             double t;
             uint32_t face = kNone;
-            const bool found = box_closest(sc, sc.boxes + (ref & kRefIndexMask), r, tmin, tmax, t, face);
+            const bool found = box_closest(sc, get_box(sc, ref & kRefIndexMask), r, tmin, tmax, t, face);
             if (found) {
                 best.t = t;
                 best.ref = face;
@@ -1091,7 +1102,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
     Ray lr = r;
     if constexpr (T::COMPOSITE) {
         if (h.obj != kNone) {
-            o = sc.objects[h.obj];
+            o = get_object(sc, h.obj);
             lr = to_object_space(sc, o, r);
         }
     }
@@ -1129,7 +1140,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
     if constexpr (T::COMPOSITE) {
         if (h.obj != kNone) {  // back to world space, innermost transform first (R/Instance.h:53,137-147)
             for (uint32_t k = o.xf_count; k-- > 0;) {
-                Xform x = sc.xforms[o.xf_first + k];
+                Xform x = get_xform(sc, o.xf_first + k);
                 if (x.kind == XF_TRANSLATE) {
                     s.p = s.p + mk(x.a, x.b, x.c);
                 } else {
@@ -1392,6 +1403,20 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             nv.n = n;
             __syncthreads();
         }
+    }
+    if constexpr (T::COMPOSITE) {
+        // small scenes: the tables of the composite leaf test, word by word, behind the node planes (see DeviceScene)
+        auto stage = [](uint32_t off, const void *table, uint32_t bytes) {
+            if (off == kNone) return;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw + off);
+            const uint32_t *src = static_cast<const uint32_t *>(table);
+            for (uint32_t w = threadIdx.x; w < bytes / 4u; w += blockDim.x) dst[w] = src[w];
+        };
+        stage(sc.lds_quad_aa, sc.quad_aa, sc.n_quads * (uint32_t)sizeof(AAQuad));
+        stage(sc.lds_boxes, sc.boxes, sc.n_boxes * (uint32_t)sizeof(BoxRec));
+        stage(sc.lds_objects, sc.objects, sc.n_objects * (uint32_t)sizeof(ObjectRec));
+        stage(sc.lds_xforms, sc.xforms, sc.n_xforms * (uint32_t)sizeof(Xform));
+        if (sc.lds_quad_aa != kNone) __syncthreads();  // all four are staged together or not at all
     }
     SphereView sv{};
     if constexpr (T::WORLD == 2) {
@@ -1786,8 +1811,9 @@ using TBvhInstances = Traits<0, true, false, RT_WAVES_INSTANCES, false>;  // ins
 using TBvhMedia = Traits<0, true, false, RT_WAVES_GENERAL, true>;       // + ConstantMedium (Cornell smoke)
 
 template <class T>
-hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, KernelInfo *info)
+hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream, KernelInfo *info)
 {
+    DeviceScene sc = sc_in;
     auto kernel = render_kernel<RT_STRICT, T>;
     uint32_t tiles = (((uint32_t)a.width + 7u) >> 3) * (((uint32_t)a.rows_owned + 7u) >> 3);
     size_t lds = 0;
@@ -1797,6 +1823,24 @@ hipError_t launch_one(const DeviceScene &sc, RenderArgs a, hipStream_t stream, K
         if (need <= 60 * 1024) {  // keep >= 2 workgroups per CU resident
             lds = need;
             a.lds_nodes = 1;
+        }
+        if (T::COMPOSITE && a.lds_nodes) {
+            // the leaf-test tables of a small scene ride along (Cornell box: 2 KB)
+            const size_t b_quads = (size_t)sc.n_quads * sizeof(AAQuad), b_boxes = (size_t)sc.n_boxes * sizeof(BoxRec);
+            const size_t b_objects = (size_t)sc.n_objects * sizeof(ObjectRec), b_xforms = (size_t)sc.n_xforms * sizeof(Xform);
+            const size_t small = b_quads + b_boxes + b_objects + b_xforms;
+            size_t off = (lds + 15) & ~(size_t)15;
+            if (small <= 16 * 1024 && off + small + 64 <= 60 * 1024) {
+                sc.lds_quad_aa = (uint32_t)off;
+                off += (b_quads + 15) & ~(size_t)15;
+                sc.lds_boxes = (uint32_t)off;
+                off += (b_boxes + 15) & ~(size_t)15;
+                sc.lds_objects = (uint32_t)off;
+                off += (b_objects + 15) & ~(size_t)15;
+                sc.lds_xforms = (uint32_t)off;
+                off += (b_xforms + 15) & ~(size_t)15;
+                lds = off;
+            }
         }
     } else if (T::WORLD == 2) {
         lds = 4 * kQueueCap * 64 * sizeof(uint16_t);

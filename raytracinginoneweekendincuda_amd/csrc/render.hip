@@ -134,7 +134,6 @@ DEV Vec refract(Vec uv, Vec n, double eta)                            // R/Vec3.
     Vec par = (-sqrt(fabs(1.0 - length_sq(perp)))) * n;
     return perp + par;
 }
-DEV Vec load3(const double *p) { return mk(p[0], p[1], p[2]); }
 
 // ------------------------------------------------------------------------------------------------
 // primitive tests.  Each returns the accepted t exactly as the reference's Hit would set rec.T.

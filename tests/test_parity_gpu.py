@@ -237,6 +237,35 @@ def test_cooperative_scan_equals_pixel_parallel_scan(scene_id, world_kind):
     assert st0.rays == st1.rays == st2.rays
 
 
+def _many_spheres(n):
+    s = rt.Scene()
+    rng = np.random.default_rng(7)
+    mats = [s.Lambertian((0.7, 0.3, 0.2)), s.Metal((0.8, 0.8, 0.9), 0.05), s.Dielectric(1.5), s.Lambertian((0.2, 0.5, 0.8))]
+    items = [s.Sphere((0.0, -1000.0, 0.0), 1000.0, mats[0])]
+    for k in range(n - 1):
+        c = rng.uniform((-9, 0.15, -9), (9, 2.5, 9))
+        items.append(s.Sphere(tuple(c), float(rng.uniform(0.1, 0.3)), mats[k % 4]))
+    s.SetWorld(s.HittableList(items))
+    s.Camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 30.0, W / H, 0.1, 10.0)
+    s.Commit()
+    return s
+
+
+@pytest.mark.parametrize("n_spheres", [64, 1700])
+def test_cooperative_scans_on_other_list_sizes(n_spheres, monkeypatch):
+    """64 spheres: one 64-row plane, every group width of the grouped scan sees a ragged tail of the table.
+    1700 spheres: the sphere planes no longer fit the LDS budget, so thin waves fall back to the one-ray-at-a-time
+    cooperative scan over the global table.  RTOW_COOP_SINGLE=1 forces that older scan on the LDS planes too."""
+    s = _many_spheres(n_spheres)
+    ref, st0 = s.render(W, H, SPP, variant=0, coop_threshold=1, overdue=-1)
+    assert st0.kernel_kind == 16
+    coop, st1 = s.render(W, H, SPP, variant=0, coop_threshold=65, overdue=-1)
+    assert np.array_equal(ref.view(np.uint64), coop.view(np.uint64)) and st0.rays == st1.rays
+    monkeypatch.setenv("RTOW_COOP_SINGLE", "1")
+    single, st2 = s.render(W, H, SPP, variant=0, coop_threshold=65, overdue=-1)
+    assert np.array_equal(ref.view(np.uint64), single.view(np.uint64)) and st0.rays == st2.rays
+
+
 @pytest.mark.parametrize("scene_id,world_kind", [(11, 1), (0, 0), (4, 0), (7, 0), (8, 0)])
 def test_specialised_kernels_equal_general_kernel(scene_id, world_kind):
     fast_path, st0 = _render(scene_id, world_kind)

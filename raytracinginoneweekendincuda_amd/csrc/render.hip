@@ -1807,7 +1807,12 @@ using TBvhPrims = Traits<0, false, false, RT_WAVES_BVH>;
 using TBvhGeneral = Traits<0, true, true, RT_WAVES_GENERAL>;
 using TListGeneral = Traits<1, true, true, RT_WAVES_GENERAL>;
 using TBvhInstances = Traits<0, true, false, RT_WAVES_INSTANCES, false>;  // instances / boxes, no media, plain textures (C4)
-using TBvhMedia = Traits<0, true, false, RT_WAVES_GENERAL, true>;       // + ConstantMedium (Cornell smoke)
+// The media and general kernels need ~220 and ~300 VGPRs.  Walking a deep tree they are latency-bound -- one wave per
+// SIMD runs at half the speed of two -- so three waves with a hundred-odd registers spilled to scratch still win
+// (Cornell smoke +5 %, C5 +4.5 %).  A shallow world with expensive shading (Perlin, image texture) loses a third that
+// way, so the general kernel exists in both shapes and the launcher picks by the depth of the world's tree.
+using TBvhMedia = Traits<0, true, false, 3, true>;                      // + ConstantMedium (Cornell smoke)
+using TBvhGeneralDeep = Traits<0, true, true, 3>;
 
 template <class T>
 hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream, KernelInfo *info)
@@ -1890,6 +1895,7 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
             if (!(sc.flags & SCENE_HAS_MEDIA)) return launch_one<TBvhInstances>(sc, a, stream, info);
             return launch_one<TBvhMedia>(sc, a, stream, info);
         }
+        if (sc.n_world_nodes > 64) return launch_one<TBvhGeneralDeep>(sc, a, stream, info);
         return launch_one<TBvhGeneral>(sc, a, stream, info);
     }
     return launch_one<TListGeneral>(sc, a, stream, info);

@@ -1812,7 +1812,10 @@ using TBvhInstances = Traits<0, true, false, RT_WAVES_INSTANCES, false>;  // ins
 // (Cornell smoke +5 %, C5 +4.5 %).  A shallow world with expensive shading (Perlin, image texture) loses a third that
 // way, so the general kernel exists in both shapes and the launcher picks by the depth of the world's tree.
 using TBvhMedia = Traits<0, true, false, 3, true>;                      // + ConstantMedium (Cornell smoke)
-using TBvhGeneralDeep = Traits<0, true, true, 3>;
+#ifndef RT_WAVES_DEEP
+#define RT_WAVES_DEEP 3
+#endif
+using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP>;
 
 template <class T>
 hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream, KernelInfo *info)

@@ -18,6 +18,14 @@ class RtowError(RuntimeError):
     pass
 
 
+# rt_render_params.flags (include/rtow.h)
+FLAG_KEEP_RNG_STATE = 1     # continue the film's saved per-pixel RNG streams (progressive rendering)
+FLAG_FORCE_GENERAL = 2      # tests: general kernel even where a specialised instantiation applies
+FLAG_OVERDUE_PRIORITY = 4   # diagnostics
+FLAG_ACCUMULATE = 8         # with KEEP_RNG_STATE: add this launch's samples to the film's running sums
+FLAG_ROW_MAJOR_TILES = 16   # BVH worlds: keep the pixel queue in row-major tile order (no cost ranking)
+
+
 def lib():
     return _lib.load()
 

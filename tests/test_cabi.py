@@ -109,3 +109,12 @@ def test_binary_ppm_and_pfm_writers(tmp_path):
     body = pf.read_bytes()
     assert body.startswith(b"PF\n7 5\n-1.0\n")
     assert np.array_equal(np.frombuffer(body[len(b"PF\n7 5\n-1.0\n"):], dtype="<f4"), frame.astype(np.float32).ravel())
+
+
+def test_python_flag_constants_match_the_header():
+    import re
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "rtow.h")).read()
+    flags = re.findall(r"#define RT_FLAG_(\w+) (\d+)u", header)
+    assert len(flags) >= 5
+    for name, value in flags:
+        assert getattr(rt, "FLAG_" + name) == int(value), name

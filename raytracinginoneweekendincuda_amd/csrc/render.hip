@@ -77,14 +77,18 @@ struct NodeView {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
-// BVH node planes in LDS: six double planes (xlo, xhi, ylo, yhi, zlo, zhi) then three word planes (a, b, escape)
-DEV double lds_node_f64(uint32_t n_nodes, uint32_t plane, uint32_t node)
+// BVH nodes in LDS: one 72-byte row per node -- six doubles (xlo, xhi, ylo, yhi, zlo, zhi), three words (a, b, escape),
+// one word of padding.  One base address per visit and immediate offsets (ds_read2_b64) instead of one address per
+// field; the odd multiple of 8 bytes spreads the rows of 64 lanes standing on 64 different nodes over 32 bank
+// positions (64-byte rows would fall on 4).
+constexpr uint32_t kLdsNodeBytes = 72;
+DEV double lds_node_f64(uint32_t, uint32_t field, uint32_t node)
 {
-    return reinterpret_cast<const double *>(lds_raw)[plane * n_nodes + node];
+    return reinterpret_cast<const double *>(lds_raw + node * kLdsNodeBytes)[field];
 }
-DEV uint32_t lds_node_u32(uint32_t n_nodes, uint32_t plane, uint32_t node)
+DEV uint32_t lds_node_u32(uint32_t, uint32_t word, uint32_t node)
 {
-    return reinterpret_cast<const uint32_t *>(lds_raw + (size_t)6 * n_nodes * sizeof(double))[plane * n_nodes + node];
+    return reinterpret_cast<const uint32_t *>(lds_raw + node * kLdsNodeBytes + 48u)[word];
 }
 
 // Small tables staged in LDS (DeviceScene::lds_*): a row by byte offset off the same symbol.
@@ -1390,14 +1394,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         nv.in_lds = a.lds_nodes != 0;
         if (nv.in_lds) {
             const uint32_t n = sc.n_world_nodes;
-            double *planes = reinterpret_cast<double *>(lds_raw);
-            uint32_t *words = reinterpret_cast<uint32_t *>(planes + 6 * (size_t)n);
             for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
                 BvhNodeRec node = sc.nodes[k];
-                planes[0 * n + k] = node.xlo; planes[1 * n + k] = node.xhi;
-                planes[2 * n + k] = node.ylo; planes[3 * n + k] = node.yhi;
-                planes[4 * n + k] = node.zlo; planes[5 * n + k] = node.zhi;
-                words[0 * n + k] = node.a; words[1 * n + k] = node.b; words[2 * n + k] = node.escape;
+                double *row = reinterpret_cast<double *>(lds_raw + k * kLdsNodeBytes);
+                uint32_t *words = reinterpret_cast<uint32_t *>(lds_raw + k * kLdsNodeBytes + 48u);
+                row[0] = node.xlo; row[1] = node.xhi; row[2] = node.ylo; row[3] = node.yhi; row[4] = node.zlo; row[5] = node.zhi;
+                words[0] = node.a; words[1] = node.b; words[2] = node.escape;
             }
             nv.n = n;
             __syncthreads();
@@ -1826,7 +1828,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
     size_t lds = 0;
     a.lds_nodes = 0;
     if (T::WORLD == 0) {
-        size_t need = (size_t)sc.n_world_nodes * (6 * sizeof(double) + 3 * sizeof(uint32_t));
+        size_t need = (size_t)sc.n_world_nodes * kLdsNodeBytes;
         if (need <= 60 * 1024) {  // keep >= 2 workgroups per CU resident
             lds = need;
             a.lds_nodes = 1;

@@ -618,13 +618,21 @@ DEV bool box_test(double xlo, double xhi, double ylo, double yhi, double zlo, do
 // tested where the node is visited; "pop" is the escape link.  The walk is resumable: a lane keeps its
 // position (node index, closest hit so far) in registers, so that the kernel can interleave traversal
 // bursts with shading and never makes 63 lanes wait for the one ray that visits 150 nodes.
+constexpr uint32_t kWalkParked = 0x80000000u;
+DEV bool walk_moving(uint32_t state) { return (int32_t)state >= 0; }
+DEV bool walk_parked(uint32_t state) { return (int32_t)state < -1; }
+
 struct Walk {
     Vec inv;          // 1 / direction (R/AABB.h:77,84,91 recompute it per node; same value)
     double a;         // dot(d, d)
     double closest;
-    uint32_t node;    // next node to visit; kNone = finished
+    // Where the lane stands, in one word so that each of the wave's three questions is a single compare:
+    //   moving  (state >= 0 as int32): `state` is the next node to visit;
+    //   parked  (bit 31 set, not kNone): standing on bottom node `state & 0x7FFFFFFF` whose box was hit -- its leaves
+    //           are tested in the next leaf phase;
+    //   done    (kNone): the walk is complete (or no walk is in progress).
+    uint32_t state;
     bool any;
-    bool at_leaves;   // standing on a bottom node whose box was hit: its leaves are tested in the next leaf phase
 };
 
 DEV void walk_begin(Walk &w, const Ray &r, double tmax)
@@ -632,15 +640,14 @@ DEV void walk_begin(Walk &w, const Ray &r, double tmax)
     w.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     w.a = dot(r.d, r.d);
     w.closest = tmax;
-    w.node = 0;
+    w.state = 0;
     w.any = false;
-    w.at_leaves = false;
 }
 
 // One inner-node step: box test, then descend / escape; a bottom node whose box is hit parks the lane.
 DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
 {
-    const uint32_t n = w.node;
+    const uint32_t n = w.state;
     double xlo, xhi, ylo, yhi, zlo, zhi;
     uint32_t na, next;
     if (nv.in_lds) {
@@ -655,18 +662,18 @@ DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
     if (box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest)) {
         if ((na >> kRefShift) == REF_INNER) next = n + 1;
         else {
-            w.at_leaves = true;
+            w.state = n | kWalkParked;
             return;  // stay on this node until the leaf phase
         }
     }
-    w.node = next;
+    w.state = next;
 }
 
 // Leaf phase for a parked lane: the bottom node's one or two leaves, in the reference's order.
 template <class T>
 DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng PH_ARG)
 {
-    const uint32_t n = w.node;
+    const uint32_t n = w.state & ~kWalkParked;
     uint32_t na, nb, next;
     if (nv.in_lds) {
         na = lds_node_u32(nv.n, 0, n); nb = lds_node_u32(nv.n, 1, n); next = lds_node_u32(nv.n, 2, n);
@@ -700,8 +707,7 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
                 best.ref = nb;
                 best.obj = kNone;
             }
-            w.node = next;
-            w.at_leaves = false;
+            w.state = next;
             return;
         }
     }
@@ -712,8 +718,7 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
             w.closest = best.t;
         }
     }
-    w.node = next;
-    w.at_leaves = false;
+    w.state = next;
 }
 
 // HittableList world (R/HittableList.h:39-57): the item index is wave-uniform, so the primitive rows
@@ -1461,11 +1466,11 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     int boost_left = 0;     // extra overdue-only passes still allowed before the next pixel-parallel pass
     // BVH worlds: per-lane resumable traversal (see Walk) and the hit it has found so far
     Walk walk{};
+    walk.state = kNone;  // no walk in progress
     HitInfo walk_best;
     walk_best.t = 0.0;
     walk_best.ref = kNone;
     walk_best.obj = kNone;
-    bool walking = false;
 
 #if RT_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicMin(a.ray_counter + 5, (unsigned long long)wall_clock64());
@@ -1536,7 +1541,6 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         active = true;
                         if constexpr (T::WORLD == 0) {
                             walk_begin(walk, ray, DBL_MAX);
-                            walking = true;
                         }
                     }
                 }
@@ -1577,12 +1581,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
             // many lanes at once instead of trailing every node visit with a few.
             for (int round = 0; round < kRounds; round++) {
                 for (int step = 0; step < (T::COMPOSITE ? a.node_burst : kBurst); step++) {
-                    const bool mover = walking && !walk.at_leaves;
+                    const bool mover = walk_moving(walk.state);
 #if RT_SIMPLE_BREAK
                     if (!__any(mover)) break;
 #else
                     const int movers = __popcll(__ballot(mover));
-                    const int parked = __popcll(__ballot(walking && walk.at_leaves));
+                    const int parked = __popcll(__ballot(walk_parked(walk.state)));
                     // most walkers are waiting at leaves: go test them.  A composite leaf (box, instance, medium) costs
                     // tens of node steps, so there the leaf phase waits for a larger share of the walkers.
                     if (movers == 0 || movers * (T::COMPOSITE ? a.park_ratio : 1) < parked) break;
@@ -1591,32 +1595,27 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         PH_BEGIN();
                         if (mover) {
                             walk_node(nv, ray, 0.001, walk);
-                            walking = walk.node != kNone;
                             // Primitive worlds (deep BVH, cheap leaves): a second visit before the next look at the
                             // wave's state -- the ballots and counts that steer the phases cost a fifth of a node visit.
                             // Not for composite worlds: the Cornell box's tree is three levels deep (measured -17 %).
                             if constexpr (!T::COMPOSITE) {
-                                if (walking && !walk.at_leaves) {
-                                    walk_node(nv, ray, 0.001, walk);
-                                    walking = walk.node != kNone;
-                                }
+                                if (walk_moving(walk.state)) walk_node(nv, ray, 0.001, walk);
                             }
                         }
                         PH_END(0, mover);
                     }
                 }
                 {
-                    const bool at_leaf = walking && walk.at_leaves;
+                    const bool at_leaf = walk_parked(walk.state);
                     PH_BEGIN();
                     if (at_leaf) {
                         walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng PH_PASS);
-                        walking = walk.node != kNone;
                     }
                     if (__any(at_leaf)) PH_END(1, at_leaf);
                 }
-                if (!__any(walking)) break;
+                if (!__any(walk.state != kNone)) break;
             }
-            const unsigned long long walkers = __ballot(walking);
+            const unsigned long long walkers = __ballot(walk.state != kNone);
             const unsigned long long waiting = live & ~walkers;
             const int n_wait = __popcll(waiting), n_walk = __popcll(walkers);
             todo = (n_wait >= a.shade_batch || n_wait >= n_walk) ? waiting : 0ull;
@@ -1676,10 +1675,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 }
             }
             if constexpr (T::WORLD == 0) {
-                if (active) {
-                    walk_begin(walk, ray, DBL_MAX);
-                    walking = true;
-                }
+                if (active) walk_begin(walk, ray, DBL_MAX);
             }
         }
 #if RT_PHASES

@@ -84,11 +84,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 constexpr uint32_t kLdsNodeBytes = 72;
 DEV double lds_node_f64(uint32_t, uint32_t field, uint32_t node)
 {
-    return reinterpret_cast<const double *>(lds_raw + node * kLdsNodeBytes)[field];
+    return reinterpret_cast<const double *>(lds_raw + __umul24(node, kLdsNodeBytes))[field];  // node < 2^24: 24-bit multiply
 }
 DEV uint32_t lds_node_u32(uint32_t, uint32_t word, uint32_t node)
 {
-    return reinterpret_cast<const uint32_t *>(lds_raw + node * kLdsNodeBytes + 48u)[word];
+    return reinterpret_cast<const uint32_t *>(lds_raw + __umul24(node, kLdsNodeBytes) + 48u)[word];
 }
 
 // Small tables staged in LDS (DeviceScene::lds_*): a row by byte offset off the same symbol.
@@ -659,14 +659,11 @@ DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
         xlo = node->xlo; xhi = node->xhi; ylo = node->ylo; yhi = node->yhi; zlo = node->zlo; zhi = node->zhi;
         na = node->a; next = node->escape;
     }
-    if (box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest)) {
-        if ((na >> kRefShift) == REF_INNER) next = n + 1;
-        else {
-            w.state = n | kWalkParked;
-            return;  // stay on this node until the leaf phase
-        }
-    }
-    w.state = next;
+    // selects, not branches: hit an inner node -> its first child; hit a bottom node -> park on it until the leaf phase;
+    // missed -> the escape link
+    const bool hit = box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
+    const uint32_t down = (na >> kRefShift) == REF_INNER ? n + 1u : (n | kWalkParked);
+    w.state = hit ? down : next;
 }
 
 // Leaf phase for a parked lane: the bottom node's one or two leaves, in the reference's order.

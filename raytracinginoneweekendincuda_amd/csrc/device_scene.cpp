@@ -321,8 +321,8 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     // leaves) gains nothing from waiting.
     {
         const uint32_t world_nodes = s.flat.n_world_nodes;
-        ra.node_burst = world_nodes > 64 ? 12 : 8;
-        ra.park_ratio = world_nodes > 64 ? 4 : 1;
+        ra.node_burst = world_nodes > 64 ? 24 : 8;
+        ra.park_ratio = world_nodes > 64 ? 8 : 1;
         if (const char *e = std::getenv("RTOW_BURST")) ra.node_burst = std::atoi(e);  // experiments only
         if (const char *e = std::getenv("RTOW_PARK")) ra.park_ratio = std::atoi(e);
     }

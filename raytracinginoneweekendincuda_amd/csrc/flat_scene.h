@@ -126,7 +126,7 @@ struct DeviceScene {
     uint32_t n_world_nodes;
     uint32_t n_spheres, n_mspheres, n_quads, n_objects, n_boxes, n_xforms;
     // Small scenes (Cornell box): the tables a composite leaf test chases through -- object record -> transforms ->
-    // box / quad rows -- are staged in LDS behind the node planes.  Byte offsets into the dynamic LDS block, set by
+    // box / quad rows -- are staged in LDS behind the node rows.  Byte offsets into the dynamic LDS block, set by
     // the launcher; kNone = read the global table.
     uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms;
     uint32_t flags;

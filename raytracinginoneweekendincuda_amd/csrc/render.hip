@@ -64,7 +64,7 @@ struct Surface {
     bool front;
 };
 
-// BVH nodes as the traversal sees them: SoA planes in LDS (or the global AoS table when they do not fit).
+// BVH nodes as the traversal sees them: 72-byte rows in LDS (or the global 64-byte table when they do not fit).
 // The LDS copy is addressed straight off the __shared__ symbol (see lds_node_*), never through generic pointers:
 // a pointer that may be LDS or global makes the compiler emit flat loads plus aperture arithmetic per access.
 struct NodeView {
@@ -1390,8 +1390,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     NodeView nv{};
     uint16_t *queue = nullptr;
     if constexpr (T::WORLD == 0) {
-        // BVH nodes as SoA planes in LDS: lanes of a wave sit at different nodes, and 8-byte planes spread
-        // those reads over the banks (an AoS 64-byte node would put every lane on the same 4 banks).
+        // BVH nodes in LDS, one 72-byte row each (see lds_node_f64 for the layout and why 72)
         nv.global = sc.nodes;
         nv.in_lds = a.lds_nodes != 0;
         if (nv.in_lds) {
@@ -1408,7 +1407,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         }
     }
     if constexpr (T::COMPOSITE) {
-        // small scenes: the tables of the composite leaf test, word by word, behind the node planes (see DeviceScene)
+        // small scenes: the tables of the composite leaf test, word by word, behind the node rows (see DeviceScene)
         auto stage = [](uint32_t off, const void *table, uint32_t bytes) {
             if (off == kNone) return;
             uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw + off);

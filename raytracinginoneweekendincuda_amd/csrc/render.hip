@@ -271,19 +271,20 @@ DEV bool box_closest(const DeviceScene &sc, const BoxRec &bx, const Ray &r, doub
     double closest = tmax;
     bool any = false;
 #define RT_BOX_FACE(k, P, Q)                                                                                            \
-    if (ok[k] && !(t[k] > closest)) {                                                                                   \
+    {                                                                                                                   \
+        /* straight-line: every lane evaluates every face (selects); only the sliver case branches */                   \
         const double pp = comp<P>(r.o) + t[k] * comp<P>(r.d), pq = comp<Q>(r.o) + t[k] * comp<Q>(r.d);                  \
         bool accept = pp >= comp<P>(in_lo) && pp <= comp<P>(in_hi) && pq >= comp<Q>(in_lo) && pq <= comp<Q>(in_hi);     \
         const bool outside = pp < comp<P>(out_lo) || pp > comp<P>(out_hi) || pq < comp<Q>(out_lo) || pq > comp<Q>(out_hi); \
-        if (!accept && !outside) {                                                                                      \
-            const AAQuad f = get_quad_aa(sc, quad_first + k);                                                              \
+        const bool live = ok[k] && !(t[k] > closest);                                                                   \
+        if (live && !accept && !outside) {                                                                              \
+            const AAQuad f = get_quad_aa(sc, quad_first + k);                                                           \
             accept = aa_inside<P, Q>(f.wa, f.qp, f.qq, f.ku, f.kv, r, t[k]);                                            \
         }                                                                                                               \
-        if (accept) {                                                                                                   \
-            closest = t[k];                                                                                             \
-            ref_best = make_ref(REF_QUAD, quad_first + k);                                                              \
-            any = true;                                                                                                 \
-        }                                                                                                               \
+        const bool take = live && accept;                                                                               \
+        closest = take ? t[k] : closest;                                                                                \
+        ref_best = take ? make_ref(REF_QUAD, quad_first + k) : ref_best;                                                \
+        any = any || take;                                                                                              \
     }
     RT_BOX_FACE(0, 0, 1)
     RT_BOX_FACE(1, 2, 1)

@@ -26,10 +26,11 @@ from .api import (  # noqa: F401
     FLAG_OVERDUE_PRIORITY,
     FLAG_ACCUMULATE,
     FLAG_ROW_MAJOR_TILES,
+    FLAG_ALWAYS_WALK,
 )
 
 __all__ = [
     "RtowError", "Rng", "Scene", "Film", "RenderParams", "RenderStats", "builtin_scene",
     "stripe_rows", "deinterleave", "write_ppm", "write_ppm_binary", "write_pfm", "rtwimage_bytes", "load_image", "library_path", "lib",
-    "FLAG_KEEP_RNG_STATE", "FLAG_FORCE_GENERAL", "FLAG_OVERDUE_PRIORITY", "FLAG_ACCUMULATE", "FLAG_ROW_MAJOR_TILES",
+    "FLAG_KEEP_RNG_STATE", "FLAG_FORCE_GENERAL", "FLAG_OVERDUE_PRIORITY", "FLAG_ACCUMULATE", "FLAG_ROW_MAJOR_TILES", "FLAG_ALWAYS_WALK",
 ]

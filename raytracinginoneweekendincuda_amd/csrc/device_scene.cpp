@@ -345,6 +345,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.rank = f.rank;
     ra.world_size = f.world_size;
     ra.force_general = (p->flags & RT_FLAG_FORCE_GENERAL) ? 1 : 0;
+    ra.always_walk = (p->flags & RT_FLAG_ALWAYS_WALK) ? 1 : 0;
     const DeviceScene &ds = s.device[f.device]->scene;
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
     // BVH worlds: heaviest tiles first.  A pixel's samples are one sequential chain, so the frame cannot end before

@@ -1813,6 +1813,14 @@ using TBvhMedia = Traits<0, true, false, 3, true>;                      // + Con
 #define RT_WAVES_DEEP 3
 #endif
 using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP>;
+// List scans over primitives / instances without media or table-walking textures.  Also the BVH worlds of small
+// scenes: for up to kSmallWorld leaves a scan of all of them in the tree's leaf order -- every lane on the same leaf, rows
+// through uniform loads, no node visits, no phases -- beats walking the tree (Cornell box: 8 leaves, 7 nodes).  Without
+// media no leaf draws random numbers, so the closest hit is the one the walk finds (the reference's own BVH = list
+// invariant; `tests/test_parity_gpu.py::test_small_world_scan_equals_the_bvh_walk`).
+using TListPrims = Traits<1, false, false, 3>;
+using TListInstances = Traits<1, true, false, 3, false>;
+constexpr uint32_t kSmallWorld = 16;
 
 template <class T>
 hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream, KernelInfo *info)
@@ -1889,6 +1897,10 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
     const bool rich = (sc.flags & SCENE_RICH_TEXTURES) != 0;
     if ((sc.flags & SCENE_LIST_ALL_SPHERES) && !rich && sc.n_spheres <= 65535u && !a.force_general)
         return launch_one<TSphereList>(sc, a, stream, info);
+    const bool media = (sc.flags & SCENE_HAS_MEDIA) != 0;
+    const bool scan_world = sc.world_kind == WORLD_LIST || (sc.n_world_items <= kSmallWorld && !a.always_walk);
+    if (scan_world && !rich && !media && !a.force_general)
+        return composite ? launch_one<TListInstances>(sc, a, stream, info) : launch_one<TListPrims>(sc, a, stream, info);
     if (sc.world_kind == WORLD_BVH) {
         if (!composite && !rich && !a.force_general) return launch_one<TBvhPrims>(sc, a, stream, info);
         if (!rich && !a.force_general) {

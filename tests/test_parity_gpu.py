@@ -197,6 +197,21 @@ def test_axis_aligned_quads_and_boxes_equal_the_general_quad_test(world_kind, va
     assert np.isfinite(a).all() and a.max() > 0.2
 
 
+@pytest.mark.parametrize("scene_id", [1, 4, 6, 7, 10])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_small_world_scan_equals_the_bvh_walk(scene_id, variant):
+    """BVH worlds of up to 16 leaves without media are rendered by a scan of all leaves in the tree's leaf order (every
+    lane on the same leaf, no node visits).  No leaf draws random numbers, so the closest hit is the one the walk finds:
+    the frame equals the walked one (RT_FLAG_ALWAYS_WALK = 32) bit for bit, in both builds."""
+    s = rt.builtin_scene(scene_id, 0, W, H)
+    scan, st_scan = s.render(W, H, SPP, variant=variant)
+    walk, st_walk = s.render(W, H, SPP, variant=variant, flags=32)
+    assert st_scan.kernel_kind in (8, 10), "expected a list-scan instantiation"
+    assert st_walk.kernel_kind in (0, 2), "expected a BVH instantiation"
+    assert st_scan.rays == st_walk.rays
+    assert np.array_equal(scan.view(np.uint64), walk.view(np.uint64))
+
+
 def test_full_size_rows_match_oracle(oracle):
     """Config C2 geometry (1200x800, list world): pixel RNG sequences depend on the full width, so check
     real rows of the full-size frame at low spp against the oracle."""

@@ -158,7 +158,7 @@ typedef struct rt_render_params {
 #define RT_FLAG_ACCUMULATE 8u      /* progressive: with KEEP_RNG_STATE, add this launch's samples to the film's running sums;
                                       the pixels then hold sqrt(sum / all samples so far), bit-identical to one launch of that many spp */
 #define RT_FLAG_FORCE_GENERAL 2u   /* tests: run the general kernel even where a specialised instantiation applies */
-#define RT_FLAG_ALWAYS_WALK 32u     /* BVH worlds of up to 16 leaves without media are rendered by scanning all leaves in the tree's
+#define RT_FLAG_ALWAYS_WALK 32u     /* small BVH worlds without media (up to 16 cheap leaves) are rendered by scanning all leaves in the tree's
                                       leaf order (same closest hit, no node visits); this flag walks the tree anyway */
 #define RT_FLAG_ROW_MAJOR_TILES 16u /* BVH worlds: keep the pixel queue in row-major tile order (default: a short rehearsal ranks
                                       the 8x8 tiles by rays traced and the heaviest start first; the image is the same either way) */

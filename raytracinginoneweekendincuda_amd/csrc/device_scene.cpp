@@ -171,6 +171,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_world_items = (uint32_t)f.world_items.size();
     d.n_nodes = (uint32_t)f.nodes.size();
     d.n_world_nodes = f.n_world_nodes;
+    d.scan_cost = f.scan_cost;
     d.n_spheres = (uint32_t)f.spheres.size();
     d.n_mspheres = (uint32_t)f.mspheres.size();
     d.n_quads = (uint32_t)f.quads.size();
@@ -346,6 +347,8 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.world_size = f.world_size;
     ra.force_general = (p->flags & RT_FLAG_FORCE_GENERAL) ? 1 : 0;
     ra.always_walk = (p->flags & RT_FLAG_ALWAYS_WALK) ? 1 : 0;
+    ra.small_world = 64;  // scan budget in half sphere tests, see FlatScene::scan_cost
+    if (const char *e = std::getenv("RTOW_SMALL_WORLD")) ra.small_world = std::atoi(e);  // experiments only
     const DeviceScene &ds = s.device[f.device]->scene;
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
     // BVH worlds: heaviest tiles first.  A pixel's samples are one sequential chain, so the frame cannot end before

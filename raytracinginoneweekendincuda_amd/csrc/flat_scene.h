@@ -124,6 +124,7 @@ struct DeviceScene {
     uint32_t n_world_items;
     uint32_t n_nodes;        // all threaded nodes: the world's first, then sub-BVHs of large groups
     uint32_t n_world_nodes;
+    uint32_t scan_cost;      // what testing every world leaf once costs, in half sphere tests
     uint32_t n_spheres, n_mspheres, n_quads, n_objects, n_boxes, n_xforms;
     // Small scenes (Cornell box): the tables a composite leaf test chases through -- object record -> transforms ->
     // box / quad rows -- are staged in LDS behind the node rows.  Byte offsets into the dynamic LDS block, set by

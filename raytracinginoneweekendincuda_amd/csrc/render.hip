@@ -1814,13 +1814,12 @@ using TBvhMedia = Traits<0, true, false, 3, true>;                      // + Con
 #endif
 using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP>;
 // List scans over primitives / instances without media or table-walking textures.  Also the BVH worlds of small
-// scenes: for up to kSmallWorld leaves a scan of all of them in the tree's leaf order -- every lane on the same leaf, rows
+// scenes: for up to 16 leaves within a cost budget (FlatScene::scan_cost) a scan of all of them in the tree's leaf order -- every lane on the same leaf, rows
 // through uniform loads, no node visits, no phases -- beats walking the tree (Cornell box: 8 leaves, 7 nodes).  Without
 // media no leaf draws random numbers, so the closest hit is the one the walk finds (the reference's own BVH = list
 // invariant; `tests/test_parity_gpu.py::test_small_world_scan_equals_the_bvh_walk`).
 using TListPrims = Traits<1, false, false, 3>;
 using TListInstances = Traits<1, true, false, 3, false>;
-constexpr uint32_t kSmallWorld = 16;
 
 template <class T>
 hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream, KernelInfo *info)
@@ -1898,7 +1897,7 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
     if ((sc.flags & SCENE_LIST_ALL_SPHERES) && !rich && sc.n_spheres <= 65535u && !a.force_general)
         return launch_one<TSphereList>(sc, a, stream, info);
     const bool media = (sc.flags & SCENE_HAS_MEDIA) != 0;
-    const bool scan_world = sc.world_kind == WORLD_LIST || (sc.n_world_items <= kSmallWorld && !a.always_walk);
+    const bool scan_world = sc.world_kind == WORLD_LIST || (sc.n_world_items <= 16u && sc.scan_cost <= (uint32_t)a.small_world && !a.always_walk);
     if (scan_world && !rich && !media && !a.force_general)
         return composite ? launch_one<TListInstances>(sc, a, stream, info) : launch_one<TListPrims>(sc, a, stream, info);
     if (sc.world_kind == WORLD_BVH) {

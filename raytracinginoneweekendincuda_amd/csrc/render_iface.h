@@ -37,6 +37,7 @@ struct RenderArgs {
     int32_t node_burst;     // composite BVH worlds: node visits between two leaf phases (set by the launcher)
     int32_t park_ratio;     // composite BVH worlds: the leaf phase starts once parked lanes outnumber moving ones by this factor
     int32_t lds_nodes;      // set by the launcher: BVH nodes are staged in LDS
+    int32_t small_world;    // BVH worlds without media are scanned, not walked, up to this scan cost (and 16 leaves)
     int32_t always_walk;    // BVH worlds: walk the tree even where a scan of all leaves would be used (small scenes)
     int32_t force_general;  // tests: use the general kernel even where a specialised one applies
     int32_t coop_threshold; // sphere-list kernel: below this many live lanes a wave scans cooperatively

@@ -631,6 +631,27 @@ int flatten_scene(SceneImpl &s)
     }
     fl.emit_pending();
     {
+        // What testing every leaf once costs, in half sphere tests (sphere 2, quad 3, box 12, a transform chain +4): the
+        // launcher scans a small BVH world instead of walking it when this stays under a budget.  Measured: 16 spheres
+        // scan 1.3x faster than they walk, 24 spheres and 8 free-standing boxes slower; the Cornell box (6 quads, 2
+        // instanced boxes, rays that cross every node's box) 1.4x faster.
+        uint64_t cost = 0;
+        for (uint32_t ref : f.world_items) {
+            const uint32_t tag = ref >> kRefShift, idx = ref & kRefIndexMask;
+            if (tag == REF_SPHERE || tag == REF_MSPHERE) cost += 2;
+            else if (tag == REF_QUAD) cost += 3;
+            else if (tag == REF_BOX) cost += 12;
+            else {
+                const ObjectRec &o = f.objects[idx];
+                cost += o.xf_count ? 4 : 0;
+                if (o.geom_kind == GEOM_BOX) cost += 12;
+                else if (o.geom_kind == GEOM_BVH) cost += 1000;
+                else cost += 3ull * o.count;
+            }
+        }
+        f.scan_cost = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
+    }
+    {
         bool unit_time = !f.mspheres.empty();
         for (const MSphereGeom &m : f.mspheres) unit_time &= (m.t0 == 0.0 && m.dt == 1.0);
         if (unit_time) f.flags |= SCENE_MS_UNIT_TIME;

@@ -81,6 +81,7 @@ struct FlatScene {
     uint32_t world_kind = WORLD_BVH;
     uint32_t flags = 0;
     uint32_t n_world_nodes = 0;
+    uint32_t scan_cost = 0;  // cost of testing every world leaf once (scene_builder.cpp), for the scan-or-walk choice
 };
 
 struct DeviceTables;  // device_scene.cpp

@@ -91,21 +91,37 @@ DEV uint32_t lds_node_u32(uint32_t, uint32_t word, uint32_t node)
     return reinterpret_cast<const uint32_t *>(lds_raw + __umul24(node, kLdsNodeBytes) + 48u)[word];
 }
 
+// Scene tables are immutable for the whole launch.  Reading them through the constant address space tells
+// the compiler so: a wave-uniform row then always comes through the scalar cache into SGPRs, even though the
+// kernel stores pixels inside its main loop (which defeats alias analysis for ordinary global loads).
+#define RT_CONST __attribute__((address_space(4)))
+
 // Small tables staged in LDS (DeviceScene::lds_*): a row by byte offset off the same symbol.
 template <class R>
 DEV R lds_row(uint32_t byte_off, uint32_t idx)
 {
     return *reinterpret_cast<const R *>(lds_raw + byte_off + idx * (uint32_t)sizeof(R));
 }
-DEV AAQuad get_quad_aa(const DeviceScene &sc, uint32_t i) { return sc.lds_quad_aa != kNone ? lds_row<AAQuad>(sc.lds_quad_aa, i) : sc.quad_aa[i]; }
-DEV BoxRec get_box(const DeviceScene &sc, uint32_t i) { return sc.lds_boxes != kNone ? lds_row<BoxRec>(sc.lds_boxes, i) : sc.boxes[i]; }
-DEV ObjectRec get_object(const DeviceScene &sc, uint32_t i) { return sc.lds_objects != kNone ? lds_row<ObjectRec>(sc.lds_objects, i) : sc.objects[i]; }
-DEV Xform get_xform(const DeviceScene &sc, uint32_t i) { return sc.lds_xforms != kNone ? lds_row<Xform>(sc.lds_xforms, i) : sc.xforms[i]; }
+// Tables are immutable for the whole launch: read through the constant address space, a wave-uniform index (list
+// scans) then comes through the scalar cache, a per-lane one as an ordinary (invariant) vector load.
+template <class R>
+DEV R const_row(const R *table, uint32_t i)
+{
+    static_assert(sizeof(R) % 8 == 0, "rows are whole quadwords");
+    const RT_CONST uint64_t *src = (const RT_CONST uint64_t *)(uintptr_t)(table + i);
+    union {
+        R row;
+        uint64_t w[sizeof(R) / 8];
+    } u;
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(R) / 8; k++) u.w[k] = src[k];
+    return u.row;
+}
+DEV AAQuad get_quad_aa(const DeviceScene &sc, uint32_t i) { return sc.lds_quad_aa != kNone ? lds_row<AAQuad>(sc.lds_quad_aa, i) : const_row(sc.quad_aa, i); }
+DEV BoxRec get_box(const DeviceScene &sc, uint32_t i) { return sc.lds_boxes != kNone ? lds_row<BoxRec>(sc.lds_boxes, i) : const_row(sc.boxes, i); }
+DEV ObjectRec get_object(const DeviceScene &sc, uint32_t i) { return sc.lds_objects != kNone ? lds_row<ObjectRec>(sc.lds_objects, i) : const_row(sc.objects, i); }
+DEV Xform get_xform(const DeviceScene &sc, uint32_t i) { return sc.lds_xforms != kNone ? lds_row<Xform>(sc.lds_xforms, i) : const_row(sc.xforms, i); }
 
-// Scene tables are immutable for the whole launch.  Reading them through the constant address space tells
-// the compiler so: a wave-uniform row then always comes through the scalar cache into SGPRs, even though the
-// kernel stores pixels inside its main loop (which defeats alias analysis for ordinary global loads).
-#define RT_CONST __attribute__((address_space(4)))
 template <class T>
 DEV const RT_CONST double *const_doubles(const T *p)
 {
@@ -237,7 +253,7 @@ DEV bool quad_test_at(const DeviceScene &sc, uint32_t idx, const Ray &r, double 
     case 1 + 3 * 1 + 2: return aa_quad_test<1, 2>(q, r, tmin, tmax, t);
     case 1 + 3 * 2 + 0: return aa_quad_test<2, 0>(q, r, tmin, tmax, t);
     case 1 + 3 * 2 + 1: return aa_quad_test<2, 1>(q, r, tmin, tmax, t);
-    default: return quad_test(sc.quads[idx], r, tmin, tmax, t);
+    default: return quad_test(const_row(sc.quads, idx), r, tmin, tmax, t);
     }
 }
 
@@ -309,11 +325,11 @@ DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
     uint32_t idx = ref & kRefIndexMask;
     switch (ref >> kRefShift) {
     case REF_SPHERE: {
-        SphereGeom g = sc.spheres[idx];
+        SphereGeom g = const_row(sc.spheres, idx);
         return sphere_test(r.o - mk(g.cx, g.cy, g.cz), r.d, a, g.r2, tmin, tmax, t);
     }
     case REF_MSPHERE: {
-        MSphereGeom g = sc.mspheres[idx];
+        MSphereGeom g = const_row(sc.mspheres, idx);
         return sphere_test(r.o - msphere_center(g, r.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0), r.d, a, g.r2, tmin, tmax, t);
     }
     default: {
@@ -729,7 +745,7 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
     bool any = false;
     const uint32_t n = sc.n_world_items;
     for (uint32_t k = 0; k < n; k++) {
-        uint32_t ref = sc.world_items[k];
+        const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const RT_CONST uint32_t *)(uintptr_t)sc.world_items)[k]);
         if (leaf_test<T>(sc, ref, r, a, tmin, closest, best, rng PH_PASS)) {
             any = true;
             closest = best.t;

@@ -5,15 +5,25 @@ One "step" = one full frame of the workload: RNG seeding + the render megakernel
 region, R/kernel.cu:676-691) and, for N > 1, the single RCCL gather of the row stripes to rank 0.
 
 Default workload = config C2 (BASELINE.json configs[1]): Book-1 final random-spheres scene, list world
-("no BVH"), 1200x800, 500 spp, depth 50, fp64 like the reference.  With N GPUs the frame keeps its view
-and width but gets N x the rows (1200 x 800N: N x vertical sample density), rows dealt to ranks in
-8-row stripes, so every rank renders one C2-frame's worth of pixels of the same distribution: weak scaling.
+("no BVH"), 1200x800, 500 spp, depth 50, fp64 like the reference.
+
+Multi-GPU (rows dealt to ranks in 8-row stripes, no data-path collective, one gather at frame end):
+  --scaling weak   (default) the frame keeps its view and width and gets N x the rows, so every rank renders one
+                   base frame's worth of pixels of the same distribution;
+  --scaling strong the BASELINE frame itself is striped over the N ranks (what north_star configs 4-5 do).
+  --emulate-ranks N  on ONE GPU: render rank 0..N-1 of an N-way split one after another and report
+                   max_r T_r against T_1 / N -- the scaling evidence available without an N-GPU node.
 
     python bench.py                      # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+Besides the contract's keys the JSON line carries `parity` (rows of the frame just timed against the CPU oracle at the
+full spp), `roofline` (fp64-VALU issue-slot bound; the contract's HBM algorithmic figure as a secondary key) and
+`cpu_baseline` (the oracle timed on the host cores, rank 0 at N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -26,58 +36,92 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (scene_id, world_kind, width, height, spp, description)
-    "c2": (11, 1, 1200, 800, 500, "C2 Book-1 final random-spheres, HittableList world (no BVH), 1200x800x500spp x50 bounces"),
-    "c3": (0, 0, 1200, 800, 500, "C3 random-spheres + MovingSphere motion blur, BvhNode world, 1200x800x500spp"),
-    "c4": (7, 0, 800, 800, 1000, "C4 Cornell box + 2 rotate/translate instances, 800x800x1000spp"),
-    "c5": (9, 0, 1600, 1600, 5000, "C5 Book-2 final scene, 1600x1600x5000spp"),
+    "c2": (11, 1, 1200, 800, 500, "C2 Book-1 final random-spheres, HittableList world (no BVH)"),
+    "c3": (0, 0, 1200, 800, 500, "C3 random-spheres + MovingSphere motion blur, BvhNode world"),
+    "c4": (7, 0, 800, 800, 1000, "C4 Cornell box + 2 rotate/translate instances"),
+    "c5": (9, 0, 1600, 1600, 5000, "C5 Book-2 final scene (BVH, Perlin + earth image textures, ConstantMedium volumes)"),
 }
 
 # Algorithmic bytes per element test, fp64: what one test minimally has to read.
 BYTES = {"box_tests": 56, "sphere_tests": 36, "msphere_tests": 76, "quad_tests": 132, "xform_entries": 44,
          "medium_calls": 16, "scatters": 32}
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TF fp32 vector rate
+# Algorithmic fp64 VALU instruction slots per element test (DESIGN.md section 4 has the derivation): the arithmetic the
+# reference's test prescribes, with a multiply-add pair counted as ONE slot where the fast build may contract it, a
+# divide or a square root as 10 (the gfx950 fp64 sequence: scale, rcp/rsq, Newton steps, fix-up).  Rays carry the
+# per-ray fixed work (1/d, d.d, hit record, camera ray share); nothing is counted for integer / RNG / control work.
+SLOTS = {"box_tests": 25, "sphere_tests": 13, "msphere_tests": 16, "quad_tests": 19, "xform_entries": 6,
+         "medium_draws": 45, "scatters": 40, "noise_calls": 140, "rays": 58}
+SLOTS_LIST_WORLD_RAY = 28     # list worlds need no 1/d per ray
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TF fp32 vector rate: one wave64 fp64 instruction per 4 cycles per SIMD
+PEAK_SLOTS_PER_S = 1024 * 2.4e9 * 64 / 4   # lane-instructions/s: 1024 SIMDs, 2.4 GHz, 16 lanes per cycle
+
+TOL = 1e-5                    # north_star: colour within 1e-5
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """Time the CPU oracle (a port, not the reference itself: the reference cannot be built here) on a
-    bounded sample of the same workload: a band of rows through the middle of the frame, few spp."""
+def earth_bytes():
+    """ImageTexture bytes of the reference's earthmap.jpg as its own stb build decodes it (committed fixture)."""
+    with np.load(os.path.join(ROOT, "tests", "golden", "earthmap_stb.npz")) as g:
+        return np.ascontiguousarray(g["bytes"])
+
+
+def oracle_band(wl, spp, max_depth, earth, budget_s=14.0):
+    """Render a band of full-width rows through the middle of the frame with the CPU oracle at the FULL spp: it is both
+    the checker for `parity` and the timed sample for `cpu_baseline` (a port, not the reference itself: the reference
+    has no CPU path and cannot be built here).  The band is as many 8-row stripes as fit the time budget."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import Oracle
-    scene_id, world, W, H, spp, _ = wl
+    scene_id, world, W, H, _, _ = wl
     orc = Oracle()
-    # the GPU box gives one GPU's share of the host: 16 cores (use fewer if the machine has fewer)
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    rows = (H // 2 - 4, H // 2 + 4)
-    orc.render(scene_id, world, W, H, 1, rows=rows, threads=cores)  # warm-up: builds the RNG jump table
+    mid = (H // 2) // 8 * 8
+    probe_rows = (mid, mid + 1)
+    orc.render(scene_id, world, W, H, 1, depth=max_depth, earth=earth, rows=probe_rows, threads=cores)  # builds the RNG jump table
     t0 = time.time()
-    orc.render(scene_id, world, W, H, 1, rows=rows, threads=cores)
-    ta = time.time() - t0
+    orc.render(scene_id, world, W, H, 2, depth=max_depth, earth=earth, rows=probe_rows, threads=cores)
+    per_row_spp = max((time.time() - t0) / 2, 1e-5)
+    n_rows = int(budget_s / (per_row_spp * spp))
+    n_rows = max(1, min(32, n_rows))
+    if n_rows >= 8:
+        n_rows = n_rows // 8 * 8
+    rows = (mid, min(H, mid + n_rows))
     t0 = time.time()
-    orc.render(scene_id, world, W, H, 5, rows=rows, threads=cores)  # calibration: per-spp cost without the fixed part
-    t1 = max((time.time() - t0 - ta) / 4, 1e-4)
-    n_spp = int(max(1, min(spp, budget_s / t1)))
-    t0 = time.time()
-    _, stats = orc.render(scene_id, world, W, H, n_spp, rows=rows, threads=cores, want_stats=True)
+    want, stats = orc.render(scene_id, world, W, H, spp, depth=max_depth, earth=earth, rows=rows, threads=cores, want_stats=True)
     dt = time.time() - t0
-    samples = W * (rows[1] - rows[0]) * n_spp
-    bytes_per_ray = sum(BYTES[k] * stats[k] for k in BYTES) / max(stats["rays"], 1)
-    return {
+    samples = W * (rows[1] - rows[0]) * spp
+    base = {
         "value": samples / dt * 1e-6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": f"rows {rows[0]}..{rows[1] - 1} of the {W}x{H} frame at {n_spp} spp ({samples} samples, {dt:.1f} s, "
-                  f"OpenMP over 8-pixel chunks, fp64, gcc -O2 -ffp-contract=off)",
+        "sample": f"rows {rows[0]}..{rows[1] - 1} of the {W}x{H} frame at the full {spp} spp ({samples} samples, {dt:.1f} s, "
+                  f"OpenMP over 8-pixel chunks, fp64, gcc -O2 -ffp-contract=off); the same rows are the parity check",
         "mray_per_s": stats["rays"] / dt * 1e-6,
-    }, bytes_per_ray, stats["rays"] / samples
+    }
+    return base, stats, want[rows[0]:rows[1]], rows
+
+
+def parity_of(got, want):
+    diff = np.abs(got - want)
+    q = lambda f: (256.0 * np.clip(f, 0.0, 0.999)).astype(np.int32)   # the PPM writer's quantisation, R/kernel.cu:710-718
+    return {
+        "within_1e-5": float(np.mean(np.all(diff <= TOL, axis=-1))),
+        "bit_exact": float(np.mean(np.all(got.view(np.uint64) == want.view(np.uint64), axis=-1))),
+        "ppm8_equal": float(np.mean(np.all(q(got) == q(want), axis=-1))),
+        "max_abs_diff": float(diff.max()),
+    }
 
 
 def measured_traffic(workload, spp, variant):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (FETCH_SIZE x2 +
-    WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes); only valid for the exact configuration profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_final_c2_pmc.json")
-    if workload != "c2" or spp != 500 or variant != "fast" or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        return json.load(f).get("hbm_bytes_per_launch")
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc pass of this very configuration
+    (FETCH_SIZE x2 + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes).  Not measured by this run: the source file
+    is named next to the number; None when no profile of this configuration is committed."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("spp", 500 if workload == "c2" else None) == spp and d.get("variant", "fast") == variant and "hbm_bytes_per_launch" in d:
+            return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -88,7 +132,13 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", default="fast", choices=["strict", "fast"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N GPUs: weak = N x the rows of the base frame (default), strong = the base frame striped over the ranks")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="one GPU: after the headline, render rank 0..N-1 of an N-way stripe split of the frame one after "
+                         "another and report max_r T_r vs T_1/N as \"emulated_scaling\"")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (no cpu_baseline, no parity)")
+    ap.add_argument("--oracle-budget", type=float, default=14.0, help="seconds of oracle work for the parity / cpu_baseline band")
     ap.add_argument("--max-depth", type=int, default=50, help="diagnostics only (the headline uses the reference's 50)")
     ap.add_argument("--coop-threshold", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--flags", type=int, default=0, help="RT_FLAG_* tuning/diagnostic bits")
@@ -121,10 +171,11 @@ def main():
     scene_id, world_kind, W, H0, spp, desc = wl
     if args.spp:
         spp = args.spp
-    H = H0 * world                                  # weak scaling: N x the rows, same view
+    H = H0 * world if args.scaling == "weak" else H0   # weak: N x the rows, same view; strong: the frame itself
     variant = 0 if args.variant == "strict" else 1
+    earth = earth_bytes() if scene_id in (2, 9) else None
 
-    scene = rt.builtin_scene(scene_id, world_kind, W, H0)     # camera aspect from the base frame
+    scene = rt.builtin_scene(scene_id, world_kind, W, H0, earth=earth)   # camera aspect from the base frame
     scene.upload(local_rank)                                  # inputs resident in HBM before timing
     film = rt.Film(W, H, device=local_rank, stripe_rows=8, rank=rank, world_size=world)
     rows_max = max(len(rt.stripe_rows(H, 8, r, world)) for r in range(world))
@@ -132,8 +183,9 @@ def main():
     film.bind_pixels(mine.data_ptr())
     gathered = [torch.empty_like(mine) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
-    params = film.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, stream=stream,
-                         coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags, shade_batch=args.shade_batch, max_blocks_per_cu=args.blocks_per_cu)
+    knobs = dict(coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags, shade_batch=args.shade_batch,
+                 max_blocks_per_cu=args.blocks_per_cu)
+    params = film.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, stream=stream, **knobs)
 
     def step():
         film.launch(scene, params)
@@ -155,7 +207,7 @@ def main():
     kernel_s, rays = [], 0
     for _ in range(args.steps):
         st = step()
-        kernel_s.append(st.seconds_render)
+        kernel_s.append(st.seconds_render)   # HIP events recorded on the stream the kernel is launched on
         rays = st.rays
     fence()
     elapsed = time.perf_counter() - t0
@@ -166,9 +218,7 @@ def main():
         its slot is reused.  The next frame's waves occupy the SIMDs the current frame's tail (a few long pixels) leaves
         idle.  Reported beside the headline, never as it."""
         films = [rt.Film(W, H, device=local_rank) for _ in range(depth)]
-        plist = [f.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, stream=0,
-                          coop_threshold=args.coop_threshold, overdue=args.overdue, flags=args.flags,
-                          shade_batch=args.shade_batch, max_blocks_per_cu=args.blocks_per_cu) for f in films]
+        plist = [f.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, stream=0, **knobs) for f in films]
         busy = [False] * depth
 
         def run(n):
@@ -191,6 +241,20 @@ def main():
 
     pipe_elapsed = pipelined(args.pipeline) if (world == 1 and args.pipeline > 1) else None
 
+    def emulate(n_ranks):
+        """Rank r of an n_ranks-way stripe split of the BASELINE frame, one rank after another on this one GPU."""
+        per_rank = []
+        for r in range(n_ranks):
+            f = rt.Film(W, H0, device=local_rank, stripe_rows=8, rank=r, world_size=n_ranks)
+            p = f.params(spp, max_depth=args.max_depth, seed=1984, variant=variant, **knobs)
+            f.render(scene, p.samples_per_pixel, max_depth=args.max_depth, variant=variant, **knobs)   # warm-up
+            ts = []
+            for _ in range(max(1, min(args.steps, 3))):
+                s_ = f.render(scene, p.samples_per_pixel, max_depth=args.max_depth, variant=variant, **knobs)
+                ts.append(s_.seconds_seed + s_.seconds_render)
+            per_rank.append(float(np.mean(ts)) * 1e3)
+        return per_rank
+
     t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone()
@@ -204,53 +268,84 @@ def main():
     if rank == 0:
         samples_per_step = W * H * spp
         value = samples_per_step * args.steps / elapsed * 1e-6
+        kernel_avg = float(np.mean(kernel_s))
+        workload = f"{desc}, {W}x{H0}x{spp}spp x{args.max_depth} bounces"
+        if world > 1:
+            workload += (f"; {world} GPUs, weak scaling: {W}x{H} (same view, {world}x rows)" if args.scaling == "weak"
+                         else f"; {world} GPUs, strong scaling: the {W}x{H} frame itself") + ", 8-row stripes round-robin, one RCCL gather"
         out = {
             "metric": "Msamples/s (pixels x spp / s), whole job",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc + (f"; {world} GPUs: {W}x{H} (same view, {world}x rows), 8-row stripes round-robin, one RCCL gather"
-                                           if world > 1 else ""),
-                       "frames_in_flight": 1, "width": W, "height": H, "spp": spp, "max_depth": 50, "seed": 1984, "variant": args.variant,
+            "config": {"workload": workload, "frames_in_flight": 1, "width": W, "height": H, "spp": spp,
+                       "max_depth": args.max_depth, "seed": 1984, "variant": args.variant,
                        "rng": "XORWOW (cuRAND device-API semantics), one sequence per pixel"},
             "mray_per_s_total": total_rays / (elapsed / args.steps) * 1e-6,
             "mray_per_s_per_gpu": total_rays / world / (elapsed / args.steps) * 1e-6,
             "rays_per_sample": total_rays / samples_per_step,
-            "kernel": {"name": "render_kernel", "avg_ms": float(np.mean(kernel_s)) * 1e3, "seed_ms": seed_s * 1e3,
-                       "vgprs": st.kernel_vgprs, "lds_bytes": st.lds_bytes},
+            "kernel": {"name": "render_kernel", "avg_ms": kernel_avg * 1e3, "seed_ms": seed_s * 1e3,
+                       "vgprs": st.kernel_vgprs, "lds_bytes": st.lds_bytes, "kind": st.kernel_kind},
         }
         if pipe_elapsed is not None:
             out["pipelined"] = {"frames_in_flight": args.pipeline, "value": samples_per_step * args.steps / pipe_elapsed * 1e-6,
                                 "unit": "Msamples/s", "ms_per_step": pipe_elapsed / args.steps * 1e3,
                                 "note": "same K frames, launched on per-film HIP streams so that frame k+1 fills the SIMDs "
                                         "frame k's tail leaves idle; a throughput mode for frame sequences, not the headline"}
-        bytes_per_ray = None
-        info_spheres = scene.info()["n_spheres"] if world_kind == 1 else 0
+        if world == 1 and args.emulate_ranks > 1:
+            per_rank = emulate(args.emulate_ranks)
+            t1_ms = kernel_avg * 1e3 + seed_s * 1e3
+            out["emulated_scaling"] = {
+                "ranks": args.emulate_ranks, "scaling": "strong", "frame": f"{W}x{H0}x{spp}spp", "t1_ms": t1_ms,
+                "per_rank_ms": per_rank, "max_rank_ms": max(per_rank),
+                "speedup": t1_ms / max(per_rank), "efficiency": t1_ms / max(per_rank) / args.emulate_ranks,
+                "note": "rank r's stripes rendered alone on this one GPU (seed + render kernels, HIP events); an N-GPU run "
+                        "finishes with its slowest rank plus one gather of a few MB"}
         if world == 1 and not args.no_cpu_baseline:
-            base, bytes_per_ray, _ = cpu_baseline(wl)
+            base, stats, want, rows = oracle_band(wl, spp, args.max_depth, earth, args.oracle_budget)
             out["cpu_baseline"] = base
-        if bytes_per_ray is None:
-            info = scene.info()
-            bytes_per_ray = info["n_spheres"] * BYTES["sphere_tests"] if world_kind == 1 else None
-        if bytes_per_ray is not None:
-            rays_rank0 = float(rays)
-            achieved = bytes_per_ray * rays_rank0 / float(np.mean(kernel_s)) * 1e-9
+            # ---- parity: the rows of the frame just timed against the oracle at the full spp ----
+            frame = film.download()
+            par = {"variant": args.variant, "rows": [rows[0], rows[1] - 1], "width": W, "spp": spp, "tolerance": TOL,
+                   "checker": "oracle/rtow_oracle.c (CPU restatement; parity unpinned, see DESIGN.md section 2)"}
+            par.update(parity_of(frame[rows[0]:rows[1]], want))
+            # the other build on the same rows: each 8-row stripe rendered on its own through the stripe partition
+            other = 1 - variant
+            n_stripes = (H + 7) // 8
+            got_other = np.zeros_like(want)
+            for k in range(rows[0] // 8, (rows[1] + 7) // 8):
+                f2 = rt.Film(W, H, device=local_rank, stripe_rows=8, rank=k, world_size=n_stripes)
+                f2.render(scene, spp, max_depth=args.max_depth, variant=other)
+                band = f2.download()[k * 8:min(H, k * 8 + 8)]
+                lo, hi = max(rows[0], k * 8), min(rows[1], k * 8 + 8)
+                got_other[lo - rows[0]:hi - rows[0]] = band[lo - k * 8:hi - k * 8]
+            par["other_variant"] = dict(variant="strict" if other == 0 else "fast", **parity_of(got_other, want))
+            out["parity"] = par
+            # ---- roofline: fp64 VALU issue slots (the limiter); the contract's HBM algorithmic figure beside it ----
+            n_rays = max(stats["rays"], 1)
+            slots = dict(SLOTS)
+            if world_kind == 1:
+                slots["rays"] = SLOTS_LIST_WORLD_RAY
+            slots_per_ray = sum(slots[k] * stats[k] for k in slots) / n_rays
+            bytes_per_ray = sum(BYTES[k] * stats[k] for k in BYTES) / n_rays
+            slots_per_s = slots_per_ray * float(rays) / kernel_avg
+            achieved_tf = slots_per_s * 2 * 1e-12     # issue-slot equivalent: the peak counts every slot as an FMA (2 flop)
+            traffic, traffic_src = measured_traffic(args.workload, spp, args.variant)
             out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.workload, spp, args.variant),
-                "algorithmic_bytes_per_ray": bytes_per_ray,
-                "note": "algorithmic bytes (SURVEY 8d element sizes x oracle-counted tests per ray) / HIP-event kernel time; "
-                        "the tables are chip-resident (scalar cache / L2), so frac may exceed 1: the true limiter is fp64 VALU",
+                "bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_source": traffic_src if traffic is not None else "not measured in this run; no committed PMC profile of this configuration",
+                "slots_per_ray": slots_per_ray, "slots_per_s": slots_per_s, "peak_slots_per_s": PEAK_SLOTS_PER_S,
+                "tests_per_ray": {k: stats[k] / n_rays for k in slots if k != "rays"},
+                "note": "achieved = algorithmic fp64 VALU instruction slots per ray (oracle-counted element tests x the slot table "
+                        "in bench.py / DESIGN.md) x rays of the timed launch / HIP-event kernel time, expressed at 2 flop per slot "
+                        "against the 78.6 TFLOP/s vector-fp64 peak (one wave64 instruction per 4 cycles per SIMD at 2.4 GHz)",
+                "hbm_algorithmic": {
+                    "achieved": bytes_per_ray * float(rays) / kernel_avg * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": bytes_per_ray * float(rays) / kernel_avg * 1e-9 / HBM_PEAK_GBS, "bytes_per_ray": bytes_per_ray,
+                    "note": "SURVEY 8d definition (element sizes x oracle-counted tests per ray / kernel time); the tables are "
+                            "chip-resident (scalar cache / LDS / L2), so this is not a bound and may exceed 1"},
             }
-            if world_kind == 1 and info_spheres:
-                # the limiter: fp64 VALU.  13 fp64 instructions per ray-sphere test (fast build), 4 cycles per wave64
-                # instruction per SIMD, 1024 SIMDs, 2.4 GHz peak clock
-                tests = rays_rank0 * info_spheres
-                out["roofline"]["valu"] = {
-                    "tests_per_s": tests / float(np.mean(kernel_s)),
-                    "peak_tests_per_s": 1024 * 2.4e9 * 64 / (13 * 4),
-                    "frac": tests / float(np.mean(kernel_s)) / (1024 * 2.4e9 * 64 / (13 * 4)),
-                    "unit": "ray-sphere tests/s"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

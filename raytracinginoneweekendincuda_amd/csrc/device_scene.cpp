@@ -30,6 +30,7 @@ static int hip_fail(hipError_t e, const char *what)
 
 struct DeviceTables {
     int device = -1;
+    uint64_t generation = 0;  // SceneImpl::generation these tables were made from
     std::vector<void *> allocations;
     DeviceScene scene{};
 };
@@ -112,6 +113,7 @@ struct FilmImpl {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // begin, after seed, after render, after the counter copy
     bool seeded = false;
     bool in_flight = false;
+    SceneImpl *scene_in_flight = nullptr;  // the scene whose tables the launch in flight reads
     uint64_t last_samples = 0;
     int last_variant = 0;
     KernelInfo last_kernel{};
@@ -133,9 +135,16 @@ int rt_scene_upload(rt_scene *scene, int device)
     if (!s.committed) return fail(RT_ERR_STATE, "rt_scene_upload: scene not committed (rt_scene_commit)");
     if (int rc = select_device(device)) return rc;
     if ((int)s.device.size() <= device) s.device.resize(device + 1, nullptr);
-    if (s.device[device]) return RT_OK;
+    if (s.device[device]) {
+        if (s.device[device]->generation == s.generation) return RT_OK;
+        // The scene was re-committed or its camera changed since this copy was made.  Nothing can still be reading
+        // it: commit / set_camera refuse while a launch is in flight.
+        release_device_tables(s.device[device]);
+        s.device[device] = nullptr;
+    }
     DeviceTables *dt = new DeviceTables;
     dt->device = device;
+    dt->generation = s.generation;
     const FlatScene &f = s.flat;
     DeviceScene &d = dt->scene;
     int rc = RT_OK;
@@ -234,6 +243,10 @@ void rt_film_destroy(rt_film *film)
     if (!film) return;
     FilmImpl *f = F(film);
     hipSetDevice(f->device);
+    if (f->in_flight) {  // destroyed without rt_render_finish: wait for the kernel, give the scene its count back
+        if (f->ev[3]) hipEventSynchronize(f->ev[3]);
+        if (f->scene_in_flight) f->scene_in_flight->launches_in_flight--;
+    }
     if (f->own_pixels) hipFree(f->own_pixels);
     if (f->accum) hipFree(f->accum);
     if (f->state) hipFree(f->state);
@@ -267,6 +280,9 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
         return fail(RT_ERR_INVALID, "rt_render_launch: params do not match the film's geometry/device");
     if (p->samples_per_pixel < 0 || p->max_depth < 0) return fail(RT_ERR_INVALID, "rt_render_launch: negative spp/depth");
     if (p->variant != 0 && p->variant != 1) return fail(RT_ERR_INVALID, "rt_render_launch: variant must be 0 (strict) or 1 (fast)");
+    if (f.in_flight)
+        return fail(RT_ERR_STATE, "rt_render_launch: this film already has a render in flight (rt_render_finish it first; "
+                                  "use one film per frame in flight)");
     if (int rc = rt_scene_upload(scene, f.device)) return rc;
     if (int rc = select_device(f.device)) return rc;
     hipStream_t stream = p->stream ? (hipStream_t)p->stream : f.own_stream;
@@ -387,6 +403,8 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     HIP_TRY(hipEventRecord(f.ev[3], stream));
     f.last_stream = stream;
     f.in_flight = true;
+    f.scene_in_flight = &s;
+    s.launches_in_flight++;
     f.last_samples = (uint64_t)f.n_pixels * (uint64_t)p->samples_per_pixel;
     f.last_variant = p->variant;
     return RT_OK;
@@ -401,6 +419,10 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
     if (int rc = select_device(f.device)) return rc;
     HIP_TRY(hipEventSynchronize(f.ev[3]));
     f.in_flight = false;
+    if (f.scene_in_flight) {
+        f.scene_in_flight->launches_in_flight--;
+        f.scene_in_flight = nullptr;
+    }
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         float ms_seed = 0, ms_render = 0;

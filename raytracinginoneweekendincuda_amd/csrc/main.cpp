@@ -102,6 +102,46 @@ static int render_multi_gpu(rt_scene *scene, rt_render_params base, int n_gpus, 
     return rc;
 }
 
+// Binary PPM (P6, maxval 255) -> RGB bytes, row 0 = top: the layout RtwImage hands to ImageTexture (R/RtwImage.h:51-92).
+static bool read_p6(const std::string &path, std::vector<unsigned char> &rgb, int &w, int &h)
+{
+    FILE *fp = std::fopen(path.c_str(), "rb");
+    if (!fp) return false;
+    auto token = [&](char *buf, size_t cap) {  // header tokens, '#' comments skipped
+        size_t n = 0;
+        int c = std::fgetc(fp);
+        while (c != EOF) {
+            if (c == '#') {
+                while (c != EOF && c != '\n') c = std::fgetc(fp);
+            } else if (c == ' ' || c == '\t' || c == '\n' || c == '\r') {
+                c = std::fgetc(fp);
+            } else {
+                break;
+            }
+        }
+        while (c != EOF && !(c == ' ' || c == '\t' || c == '\n' || c == '\r') && n + 1 < cap) {
+            buf[n++] = (char)c;
+            c = std::fgetc(fp);
+        }
+        buf[n] = 0;
+        return n > 0;
+    };
+    char magic[8], sw[16], sh[16], smax[16];
+    bool ok = token(magic, sizeof magic) && std::strcmp(magic, "P6") == 0 && token(sw, sizeof sw) && token(sh, sizeof sh) &&
+              token(smax, sizeof smax) && std::atoi(smax) == 255;
+    if (ok) {
+        w = std::atoi(sw);
+        h = std::atoi(sh);
+        ok = w > 0 && h > 0 && (long long)w * h < (1ll << 28);
+    }
+    if (ok) {
+        rgb.resize((size_t)w * h * 3);
+        ok = std::fread(rgb.data(), 1, rgb.size(), fp) == rgb.size();
+    }
+    std::fclose(fp);
+    return ok;
+}
+
 static int die(const char *what)
 {
     std::fprintf(stderr, "%s: %s\n", what, rt_last_error());
@@ -113,6 +153,8 @@ int main(int argc, char **argv)
     int width = 1440, height = 720, scene_id = 9, spp = -1, depth = 50, world_kind = 0, variant = 1, device = 0, gpus = 0;
     unsigned long long seed = 1984;
     std::string out = "output.ppm";
+    std::string earth_path;      // decoded 8-bit sRGB pixels of the earth texture (P6): converted like RtwImage::Load does
+    bool earth_is_bytes = false; // --earth-bytes: the file already holds what RtwImage::Load hands to ImageTexture
     for (int k = 1; k < argc; k++) {
         std::string a = argv[k];
         auto val = [&](const char *name) -> const char * {
@@ -130,10 +172,18 @@ int main(int argc, char **argv)
         else if (const char *v = val("--device")) device = std::atoi(v);
         else if (const char *v = val("--gpus")) gpus = std::atoi(v);  // >= 1: stripe the frame over that many GPUs + one RCCL gather
         else if (const char *v = val("--output")) out = v;
-        else {
+        else if (const char *v = val("--earth")) earth_path = v;
+        else if (const char *v = val("--earth-bytes")) {
+            earth_path = v;
+            earth_is_bytes = true;
+        } else {
             std::fprintf(stderr,
                          "usage: rtow [--scene 0..11] [--width W] [--height H] [--spp N] [--depth D] [--seed S]\n"
-                         "            [--world bvh|list] [--variant strict|fast] [--device N] [--gpus N] [--output file.ppm]\n");
+                         "            [--world bvh|list] [--variant strict|fast] [--device N] [--gpus N] [--output file.ppm]\n"
+                         "            [--earth decoded.ppm | --earth-bytes texture.ppm]\n"
+                         "  --earth        binary PPM (P6) of earthmap.jpg as decoded to 8-bit sRGB (e.g. `djpeg earthmap.jpg`); it is\n"
+                         "                 linearised and re-quantised exactly as the reference's RtwImage::Load does\n"
+                         "  --earth-bytes  binary PPM (P6) that already holds the bytes RtwImage::Load hands to ImageTexture\n");
             return 2;
         }
     }
@@ -141,7 +191,34 @@ int main(int argc, char **argv)
 
     std::fprintf(stderr, "Rendering a %dx%d image with %d samples per pixel in 8x8 blocks.\n", width, height, spp);
     rt_scene *scene = rt_scene_create();
-    if (rt_scene_build_builtin(scene, scene_id, world_kind, width, height, seed, nullptr, 0, 0) != RT_OK) return die("scene");
+    // R/kernel.cu:656-665: scenes 2 and 9 load earthmap.jpg through stb_image.  This executable carries no JPEG decoder:
+    // the decoded pixels come in as a PPM (--earth / --earth-bytes; ./earthmap.ppm is picked up like the reference picks
+    // up ./earthmap.jpg).  Without one the sphere shows the reference's own fallback for a missing file, cyan
+    // (R/Texture.h:113-114) -- and the picture then differs from the reference's, which ships the file.
+    std::vector<unsigned char> earth;
+    int earth_w = 0, earth_h = 0;
+    if (scene_id == 2 || scene_id == 9) {
+        if (earth_path.empty()) {
+            if (FILE *probe = std::fopen("earthmap.ppm", "rb")) {
+                std::fclose(probe);
+                earth_path = "earthmap.ppm";
+            }
+        }
+        if (earth_path.empty()) {
+            std::fprintf(stderr, "ERROR: Could not load image file 'earthmap.ppm' (pass --earth <decoded earthmap.jpg as P6 PPM>); "
+                                 "the image texture renders cyan.\n");
+        } else if (!read_p6(earth_path, earth, earth_w, earth_h)) {
+            std::fprintf(stderr, "ERROR: Could not load image file '%s'.\n", earth_path.c_str());
+            earth.clear();
+            earth_w = earth_h = 0;
+        } else {
+            if (!earth_is_bytes) rt_rtwimage_bytes(earth.data(), earth.size(), earth.data());
+            std::fprintf(stderr, "Loaded image '%s' (%dx%d) and uploaded to device.\n", earth_path.c_str(), earth_w, earth_h);
+        }
+    }
+    if (rt_scene_build_builtin(scene, scene_id, world_kind, width, height, seed, earth.empty() ? nullptr : earth.data(), earth_w,
+                               earth_h) != RT_OK)
+        return die("scene");
 
     rt_render_params p{};
     p.width = width;

@@ -571,10 +571,14 @@ int flatten_scene(SceneImpl &s)
 {
     if (s.world == 0) return fail(RT_ERR_STATE, "rt_scene_commit: no world set (rt_scene_set_world)");
     if (!s.has_camera) return fail(RT_ERR_STATE, "rt_scene_commit: no camera set (rt_scene_set_camera)");
+    if (s.launches_in_flight > 0)
+        return fail(RT_ERR_STATE, "rt_scene_commit: a render of this scene is in flight (rt_render_finish it first)");
+    s.committed = false;
+    s.generation++;  // device copies made from the previous tables are stale from here on
     s.flat = FlatScene{};
     FlatScene &f = s.flat;
     lower_materials(s, f);
-    Flattener fl{s, f, {}};
+    Flattener fl{s, f, {}, {}};
 
     const HostHittable &world = s.hittables[s.world - 1];
     std::vector<uint32_t> leaves;  // hittable handles, final order
@@ -1053,6 +1057,8 @@ int rt_scene_set_camera(rt_scene *s, const double lookfrom[3], const double look
                         double time1, const double background[3])
 {
     if (!s || !lookfrom || !lookat || !vup || !background) return fail(RT_ERR_INVALID, "rt_scene_set_camera: null argument");
+    if (S(s)->launches_in_flight > 0)
+        return fail(RT_ERR_STATE, "rt_scene_set_camera: a render of this scene is in flight (rt_render_finish it first)");
     // Camera.h:47-72
     CameraRec c{};
     D3 from = mk(lookfrom[0], lookfrom[1], lookfrom[2]), at = mk(lookat[0], lookat[1], lookat[2]);
@@ -1080,6 +1086,7 @@ int rt_scene_set_camera(rt_scene *s, const double lookfrom[3], const double look
     c.time1 = time1;
     S(s)->camera = c;
     S(s)->has_camera = true;
+    S(s)->generation++;  // the uploaded CameraRec is stale; the flat tables do not depend on the camera
     return RT_OK;
 }
 

@@ -99,6 +99,11 @@ struct SceneImpl {
     bool committed = false;
     FlatScene flat;
     std::vector<DeviceTables *> device;  // one per device ordinal, lazily
+    // Every change the device copies depend on (a commit, a new camera) bumps `generation`; rt_scene_upload replaces a
+    // device's tables when they are older.  `launches_in_flight` counts rt_render_launch calls not yet finished: the
+    // scene may not be changed while a kernel may still be reading its tables.
+    uint64_t generation = 0;
+    int launches_in_flight = 0;
 
     ~SceneImpl();
 };

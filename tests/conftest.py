@@ -76,6 +76,186 @@ class Oracle:
         return out
 
 
+class OracleRng:
+    """curand_init(seed, sequence, 0) on the oracle side (scene generation: NoiseTexture, random placement)."""
+
+    def __init__(self, seed=1984, sequence=0):
+        L = Oracle().L
+        L.oracle_rng_new.restype = C.c_void_p
+        L.oracle_rng_new.argtypes = [C.c_uint64, C.c_uint64]
+        L.oracle_rng_free.argtypes = [C.c_void_p]
+        L.oracle_rng_uniform.argtypes = [C.c_void_p]
+        L.oracle_rng_uniform.restype = C.c_float
+        self.L = L
+        self._p = L.oracle_rng_new(seed, sequence)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self.L.oracle_rng_free(self._p)
+            self._p = None
+
+    def uniform(self):
+        return self.L.oracle_rng_uniform(self._p)
+
+
+def _d3(v):
+    return (C.c_double * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+class OracleScene:
+    """The oracle's own object tree built constructor by constructor (oracle_c_* in oracle/rtow_oracle.c).  Method
+    names and argument meaning are those of raytracinginoneweekendincuda_amd.Scene (i.e. of the reference's classes), so
+    that one scene-building function can be run against both and the frames compared.  Any nesting is allowed."""
+
+    _SIGS = {
+        "oracle_c_solid": [C.c_double] * 3, "oracle_c_checker": [C.c_double, C.c_int, C.c_int],
+        "oracle_c_image": [C.c_void_p, C.c_int, C.c_int], "oracle_c_noise": [C.c_double, C.c_void_p],
+        "oracle_c_lambertian_tex": [C.c_int], "oracle_c_lambertian": [C.c_double] * 3, "oracle_c_metal": [C.c_double] * 4,
+        "oracle_c_dielectric": [C.c_double], "oracle_c_light_tex": [C.c_int], "oracle_c_light": [C.c_double] * 3,
+        "oracle_c_isotropic_tex": [C.c_int], "oracle_c_isotropic": [C.c_double] * 3,
+        "oracle_c_sphere": [C.c_double] * 4 + [C.c_int], "oracle_c_moving_sphere": [C.c_double] * 9 + [C.c_int],
+        "oracle_c_quad": [C.c_void_p] * 3 + [C.c_int], "oracle_c_translate": [C.c_int] + [C.c_double] * 3,
+        "oracle_c_rotate_y": [C.c_int, C.c_double], "oracle_c_make_box": [C.c_void_p, C.c_void_p, C.c_int],
+        "oracle_c_list": [C.c_void_p, C.c_int], "oracle_c_bvh": [C.c_void_p, C.c_int],
+        "oracle_c_medium": [C.c_int] + [C.c_double] * 4, "oracle_c_medium_tex": [C.c_int, C.c_double, C.c_int],
+        "oracle_c_bounding_box": [C.c_int, C.c_void_p], "oracle_c_set_world": [C.c_int],
+        "oracle_c_set_camera": [C.c_void_p] * 3 + [C.c_double] * 6 + [C.c_void_p],
+        "oracle_c_render": [C.c_int] * 4 + [C.c_uint64] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p],
+    }
+
+    def __init__(self):
+        L = Oracle().L
+        L.oracle_custom_new.restype = C.c_void_p
+        L.oracle_custom_free.argtypes = [C.c_void_p]
+        for name, sig in self._SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = [C.c_void_p] + sig
+            fn.restype = C.c_int
+        self.L = L
+        self._p = L.oracle_custom_new()
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self.L.oracle_custom_free(self._p)
+            self._p = None
+
+    def _h(self, handle):
+        assert handle > 0, "oracle constructor rejected its arguments"
+        return handle
+
+    # textures
+    def SolidColor(self, c):
+        return self._h(self.L.oracle_c_solid(self._p, *map(float, c)))
+
+    def CheckerTexture(self, scale, even, odd):
+        return self._h(self.L.oracle_c_checker(self._p, scale, even, odd))
+
+    def ImageTexture(self, rgb):
+        if rgb is None:
+            return self._h(self.L.oracle_c_image(self._p, None, 0, 0))
+        a = np.ascontiguousarray(rgb, dtype=np.uint8)
+        return self._h(self.L.oracle_c_image(self._p, a.ctypes.data, a.shape[1], a.shape[0]))
+
+    def NoiseTexture(self, scale, rng):
+        return self._h(self.L.oracle_c_noise(self._p, scale, rng._p))
+
+    # materials
+    def Lambertian(self, c):
+        if isinstance(c, int):
+            return self._h(self.L.oracle_c_lambertian_tex(self._p, c))
+        return self._h(self.L.oracle_c_lambertian(self._p, *map(float, c)))
+
+    def Metal(self, c, fuzz):
+        return self._h(self.L.oracle_c_metal(self._p, float(c[0]), float(c[1]), float(c[2]), fuzz))
+
+    def Dielectric(self, ior):
+        return self._h(self.L.oracle_c_dielectric(self._p, ior))
+
+    def DiffuseLight(self, c):
+        if isinstance(c, int):
+            return self._h(self.L.oracle_c_light_tex(self._p, c))
+        return self._h(self.L.oracle_c_light(self._p, *map(float, c)))
+
+    def Isotropic(self, c):
+        if isinstance(c, int):
+            return self._h(self.L.oracle_c_isotropic_tex(self._p, c))
+        return self._h(self.L.oracle_c_isotropic(self._p, *map(float, c)))
+
+    # hittables
+    def Sphere(self, center, radius, material):
+        return self._h(self.L.oracle_c_sphere(self._p, float(center[0]), float(center[1]), float(center[2]), radius, material))
+
+    def MovingSphere(self, c0, c1, t0, t1, radius, material):
+        return self._h(self.L.oracle_c_moving_sphere(self._p, *map(float, c0), *map(float, c1), t0, t1, radius, material))
+
+    def Quad(self, q, u, v, material):
+        a, b, c = _d3(q), _d3(u), _d3(v)  # keep the arrays alive across the call
+        return self._h(self.L.oracle_c_quad(self._p, C.addressof(a), C.addressof(b), C.addressof(c), material))
+
+    def Translate(self, obj, offset):
+        return self._h(self.L.oracle_c_translate(self._p, obj, *map(float, offset)))
+
+    def RotateY(self, obj, degrees):
+        return self._h(self.L.oracle_c_rotate_y(self._p, obj, degrees))
+
+    def MakeBox(self, a, b, material):
+        lo, hi = _d3(a), _d3(b)
+        return self._h(self.L.oracle_c_make_box(self._p, C.addressof(lo), C.addressof(hi), material))
+
+    def HittableList(self, items):
+        arr = (C.c_int * max(1, len(items)))(*items)
+        return self._h(self.L.oracle_c_list(self._p, C.addressof(arr), len(items)))
+
+    def BvhNode(self, items):
+        arr = (C.c_int * max(1, len(items)))(*items)
+        root = self._h(self.L.oracle_c_bvh(self._p, C.addressof(arr), len(items)))
+        items[:] = list(arr)[: len(items)]
+        return root
+
+    def ConstantMedium(self, boundary, density, c):
+        if isinstance(c, int):
+            return self._h(self.L.oracle_c_medium_tex(self._p, boundary, density, c))
+        return self._h(self.L.oracle_c_medium(self._p, boundary, density, *map(float, c)))
+
+    def BoundingBox(self, obj):
+        out = (C.c_double * 6)()
+        assert self.L.oracle_c_bounding_box(self._p, obj, C.addressof(out)) == 0
+        return list(out)
+
+    def SetWorld(self, world):
+        assert self.L.oracle_c_set_world(self._p, world) == 0
+
+    def Camera(self, lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist, time0=0.0, time1=0.0,
+               background=(0.70, 0.80, 1.00)):
+        a, b, c, d = _d3(lookfrom), _d3(lookat), _d3(vup), _d3(background)
+        assert self.L.oracle_c_set_camera(self._p, C.addressof(a), C.addressof(b), C.addressof(c), vfov, aspect, aperture,
+                                          focus_dist, time0, time1, C.addressof(d)) == 0
+
+    def Commit(self):
+        pass
+
+    def render(self, W, H, spp, depth=50, seed=1984, rows=None, threads=0, want_stats=False):
+        fb = np.zeros((H, W, 3), dtype=np.float64)
+        st = (C.c_uint64 * N_STATS)()
+        r0, r1 = rows if rows else (0, H)
+        rc = self.L.oracle_c_render(self._p, W, H, spp, depth, seed, r0, r1, threads, fb.ctypes.data,
+                                    C.addressof(st) if want_stats else None)
+        assert rc == 0
+        if want_stats:
+            return fb, dict(zip(STAT_NAMES, list(st)))
+        return fb
+
+
+def build_both(build):
+    """Run one scene-building function against the product's construction API and against the oracle's.
+    `build(s, Rng)` uses only the shared method names; returns (product scene, oracle scene)."""
+    import raytracinginoneweekendincuda_amd as rt
+    prod, orc = rt.Scene(), OracleScene()
+    build(prod, rt.Rng)
+    build(orc, OracleRng)
+    return prod, orc
+
+
 @pytest.fixture(scope="session")
 def oracle():
     return Oracle()
@@ -94,8 +274,20 @@ def synthetic_earth(seed=1984, w=256, h=128):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
+def stb_earth():
+    """The bytes the reference's RtwImage::Load hands to ImageTexture for its earthmap.jpg (1024x512 RGB), produced by the
+    reference's own stb_image build (tests/golden/make_earth_golden.py; the JPEG itself cannot travel)."""
+    with np.load(os.path.join(ROOT, "tests", "golden", "earthmap_stb.npz")) as g:
+        return np.ascontiguousarray(g["bytes"])
+
+
 @pytest.fixture(scope="session")
 def earth():
+    return stb_earth()
+
+
+@pytest.fixture(scope="session")
+def fake_earth():
     return synthetic_earth()
 
 

@@ -158,3 +158,34 @@ def test_stripe_rows_and_deinterleave():
         assert sorted(seen) == list(range(H))
         out = rt.deinterleave(np.stack(parts), W, H, 8, world)
         assert np.array_equal(out, full)
+
+
+def test_custom_scene_constructors_match_the_oracles(oracle):
+    """The construction API against the oracle's constructors on a hand-built scene (no GPU needed): every object's
+    bounding box bit for bit -- Quad / MakeBox / RotateY corner sweep / Translate re-padding / ConstantMedium / lists --
+    and the order BvhNode leaves list[] in (R/BvhNode.h:180-193)."""
+    from conftest import OracleScene
+
+    def build(s):
+        grey = s.Lambertian((0.7, 0.7, 0.7))
+        objs = [s.Quad((-1.0, 3.5, -4.0), (2.0, 0.3, 0.1), (0.2, 1.5, -0.4), grey),
+                s.Quad((0.0, 0.0, 0.0), (2.0, 0.0, 0.0), (0.0, 0.0, 3.0), grey),              # flat: padded on y
+                s.MakeBox((1000.0, -3.0, -2.0), (1001.5, -1.0, -0.5), grey),
+                s.Sphere((0.3, 0.0, -3.0), 0.8, grey),
+                s.MovingSphere((1.0, 0.2, 0.5), (1.0, 0.7, 0.5), 0.0, 1.0, 0.2, grey)]
+        objs.append(s.RotateY(objs[2], 33.0))
+        objs.append(s.Translate(objs[5], (0.1, -7.0, 2.5)))
+        objs.append(s.Translate(objs[1], (5.0, 1e-7, 0.0)))                                   # thin axis padded again
+        objs.append(s.ConstantMedium(objs[3], 0.5, (1, 1, 1)))
+        objs.append(s.HittableList([objs[0], objs[4], objs[6]]))
+        boxes = [s.BoundingBox(o) for o in objs]
+        leaves = [objs[k] for k in (9, 8, 7, 4, 0, 6, 1)]
+        before = list(leaves)
+        root = s.BvhNode(leaves)
+        boxes.append(s.BoundingBox(root))
+        return np.array(boxes), [before.index(h) for h in leaves]
+
+    pb, porder = build(rt.Scene())
+    ob, oorder = build(OracleScene())
+    assert np.array_equal(pb.view(np.uint64), ob.view(np.uint64))
+    assert porder == oorder and porder != list(range(7))

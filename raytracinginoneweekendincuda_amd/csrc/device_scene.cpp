@@ -91,7 +91,7 @@ static int select_device(int device)
     return RT_OK;
 }
 
-constexpr size_t kCounterWords = 64;
+constexpr size_t kCounterWords = 128;
 
 struct FilmImpl {
     int device = 0;
@@ -154,6 +154,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.spheres, d.spheres);
     up(f.sphere_aux, d.sphere_aux);
     up(f.mspheres, d.mspheres);
+    up(f.ms_planes, d.ms_planes);
     up(f.msphere_aux, d.msphere_aux);
     up(f.quads, d.quads);
     up(f.quad_aa, d.quad_aa);
@@ -187,7 +188,12 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_objects = (uint32_t)f.objects.size();
     d.n_boxes = (uint32_t)f.boxes.size();
     d.n_xforms = (uint32_t)f.xforms.size();
-    d.lds_quad_aa = d.lds_boxes = d.lds_objects = d.lds_xforms = kNone;
+    if (!(f.flags & SCENE_WORLD_MSPHERES)) d.ms_planes = nullptr;
+    d.ms_padded = f.ms_padded;
+    d.n_media = (uint32_t)f.media.size();
+    d.n_materials = (uint32_t)f.materials.size();
+    d.n_perlin = (uint32_t)f.perlin.size();
+    d.lds_quad_aa = d.lds_boxes = d.lds_objects = d.lds_xforms = d.lds_media = d.lds_materials = d.lds_perlin = kNone;
     d.flags = f.flags;
     s.device[device] = dt;
     return RT_OK;
@@ -342,6 +348,10 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
         ra.park_ratio = world_nodes > 64 ? 8 : 1;
         if (const char *e = std::getenv("RTOW_BURST")) ra.node_burst = std::atoi(e);  // experiments only
         if (const char *e = std::getenv("RTOW_PARK")) ra.park_ratio = std::atoi(e);
+        ra.leaf_batch = 8;
+        ra.object_batch = 4;
+        if (const char *e = std::getenv("RTOW_LEAF_BATCH")) ra.leaf_batch = std::atoi(e);
+        if (const char *e = std::getenv("RTOW_OBJECT_BATCH")) ra.object_batch = std::atoi(e);
     }
     ra.overdue_priority = (p->flags & RT_FLAG_OVERDUE_PRIORITY) ? 1 : 0;
     {
@@ -367,6 +377,9 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     if (const char *e = std::getenv("RTOW_SMALL_WORLD")) ra.small_world = std::atoi(e);  // experiments only
     const DeviceScene &ds = s.device[f.device]->scene;
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
+    // BVH sphere worlds: a walked ray costs ~20 us of dependent node visits whatever the wave holds, a scanned one a tenth
+    // of that while the wave is at most half full (scan_grouped_ms), so the switch comes earlier than for list worlds
+    if (f.last_kernel.kind < 8 && p->coop_threshold <= 0) ra.coop_threshold = 33;
     // BVH worlds: heaviest tiles first.  A pixel's samples are one sequential chain, so the frame cannot end before
     // its longest pixel does (glass: up to max_depth rays per sample).  In row-major order those pixels start
     // wherever they happen to lie and the frame ends long after the queue has drained (C3: drained at 38 ms, last
@@ -436,18 +449,19 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         }
         if (std::getenv("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;
-            const char *name[12] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
-                                           "    record+xforms", "    box", "    sub-BVH", "    other geometry"};
+            const char *name[24] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
+                                    "    record+xforms", "    box", "    sub-BVH", "    other geometry", "", "", "", "",
+                                    "box pass", "medium pass", "object pass", "primitive pass", "  hit record", "  scatter",
+                                    "  next camera ray", "  pixel done"};
             if (f.last_kernel.kind >= 16) {  // sphere-list kernel: slots 0 / 1 are its two scans
                 name[0] = "scan, pixel-parallel";
                 name[1] = "scan, cooperative";
             }
             const double total = (double)c[7];
-            for (int k = 0; k < 12; k++)
-                if (k != 7)
+            for (int k = 0; k < 24; k++)
+                if (name[k][0] && c[96 + k])
                     std::fprintf(stderr, "phase %-20s: %5.1f %% of wave time, %10llu passes, %5.1f lanes/pass, %7.0f cycles/pass\n", name[k],
-                                 100.0 * c[16 + k] / total, c[48 + k], c[48 + k] ? (double)c[32 + k] / c[48 + k] : 0.0,
-                                 c[48 + k] ? (double)c[16 + k] / c[48 + k] : 0.0);
+                                 100.0 * c[32 + k] / total, c[96 + k], (double)c[64 + k] / c[96 + k], (double)c[32 + k] / c[96 + k]);
         }
         stats->samples = f.last_samples;
         stats->rays = rays;

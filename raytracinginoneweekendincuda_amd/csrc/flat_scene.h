@@ -17,6 +17,7 @@ enum : uint32_t {
     REF_OBJECT = 3u,   // index into objects (instances / boxes / lists / media)
     REF_MEDIUM = 4u,   // only in hit results: index into media
     REF_BOX = 5u,      // leaves only: index into boxes (a MakeBox box without transform or medium; its hits are REF_QUAD)
+    REF_MOBJECT = 6u,  // leaves only: index into objects, for an object that is a ConstantMedium (its test draws random numbers)
     REF_INNER = 14u,   // BVH node marker: children are the next node and the escape target
     REF_NONE = 15u
 };
@@ -62,9 +63,13 @@ struct ObjectRec {
     uint32_t count;
     uint32_t xf_first, xf_count;
     uint32_t medium;     // index into media or kNone
-    uint32_t pad0, pad1;
+    uint32_t coop_first; // GEOM_BVH over static spheres only: their rows are spheres[coop_first .. coop_first + count), so a wave
+                         // may scan them together instead of walking the sub-BVH lane by lane; kNone otherwise
+    uint32_t pad1;
 };
-struct MediumRec { double neg_inv_density; uint32_t phase_mat; uint32_t pad; };  // R/ConstantMedium.h:39-44
+// R/ConstantMedium.h:39-44.  When the boundary is a lone Sphere without transforms (both media of the Book-2 final scene),
+// its row is repeated here so that the medium test needs no further table: sphere = its index in spheres[], else kNone.
+struct MediumRec { double neg_inv_density; uint32_t phase_mat; uint32_t sphere; double cx, cy, cz, r2; };
 
 // Threaded BVH node, preorder.  Inner node: a = b = REF_INNER marker, first child = this + 1.
 // Bottom node (span 1 or 2, R/BvhNode.h:63-72): a, b = leaf refs (a == b for span 1).
@@ -120,16 +125,22 @@ struct DeviceScene {
     const unsigned char *image_bytes;
     const PerlinRec *perlin;
     const CameraRec *camera;
+    // BVH worlds whose leaves are all spheres / unit-time moving spheres (SCENE_WORLD_MSPHERES): the leaves once more, in
+    // leaf order (entry k is world_items[k]), as seven planes of ms_padded doubles (c0x, c0y, c0z, dcx, dcy, dcz, r2; plane p
+    // at ms_planes + p * ms_padded) for the cooperative scan of thin waves (render.hip scan_grouped_ms).  nullptr otherwise.
+    const double *ms_planes;
+    uint32_t ms_padded;
     uint32_t world_kind;
     uint32_t n_world_items;
     uint32_t n_nodes;        // all threaded nodes: the world's first, then sub-BVHs of large groups
     uint32_t n_world_nodes;
     uint32_t scan_cost;      // what testing every world leaf once costs, in half sphere tests
     uint32_t n_spheres, n_mspheres, n_quads, n_objects, n_boxes, n_xforms;
-    // Small scenes (Cornell box): the tables a composite leaf test chases through -- object record -> transforms ->
-    // box / quad rows -- are staged in LDS behind the node rows.  Byte offsets into the dynamic LDS block, set by
-    // the launcher; kNone = read the global table.
-    uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms;
+    uint32_t n_media, n_materials, n_perlin;
+    // Tables a leaf test or the shading chases through -- object record -> transforms -> box / quad rows, medium rows,
+    // material rows, Perlin tables -- are staged in LDS behind the node rows where they fit.  Byte offsets into the
+    // dynamic LDS block, set by the launcher per table; kNone = read the global table.
+    uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin;
     uint32_t flags;
 };
 
@@ -138,6 +149,7 @@ enum : uint32_t {
     SCENE_LIST_ALL_SPHERES = 2u,  // WORLD_LIST whose leaves are spheres 0..n-1 in order (config C2 fast path)
     SCENE_RICH_TEXTURES = 4u,     // some texture is an ImageTexture or NoiseTexture
     SCENE_MS_UNIT_TIME = 8u,      // every moving-sphere row has time0 = 0, time1 - time0 = 1: frac == ray time
+    SCENE_WORLD_MSPHERES = 16u,   // WORLD_BVH of spheres / unit-time moving spheres only: ms_planes is filled
 };
 
 } // namespace rtow

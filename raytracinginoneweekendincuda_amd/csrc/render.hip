@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstddef>
 #include <cstdint>
 
 #include "flat_scene.h"
@@ -36,8 +37,10 @@ namespace {
 //              2 = HittableList of static spheres only (config C2: scalar-fed discriminant scan + LDS queue)
 //   COMPOSITE  instances / boxes / lists / media may appear as leaves
 //   RICH       Perlin-noise or image textures may appear
-template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_>
+//   BATCH      BVH world with composite leaves: the leaf phase runs one kind of leaf at a time (deep trees, see walk_leaf_pass)
+template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false>
 struct Traits {
+    static constexpr bool BATCH = BATCH_ && COMPOSITE_ && WORLD_ == 0;
     static constexpr bool MEDIA = MEDIA_;  // ConstantMedium leaves may appear (needs COMPOSITE)
     static constexpr int MIN_WAVES = MIN_WAVES_;  // waves per SIMD the register allocator must leave room for
     static constexpr int WORLD = WORLD_;
@@ -121,6 +124,13 @@ DEV AAQuad get_quad_aa(const DeviceScene &sc, uint32_t i) { return sc.lds_quad_a
 DEV BoxRec get_box(const DeviceScene &sc, uint32_t i) { return sc.lds_boxes != kNone ? lds_row<BoxRec>(sc.lds_boxes, i) : const_row(sc.boxes, i); }
 DEV ObjectRec get_object(const DeviceScene &sc, uint32_t i) { return sc.lds_objects != kNone ? lds_row<ObjectRec>(sc.lds_objects, i) : const_row(sc.objects, i); }
 DEV Xform get_xform(const DeviceScene &sc, uint32_t i) { return sc.lds_xforms != kNone ? lds_row<Xform>(sc.lds_xforms, i) : const_row(sc.xforms, i); }
+DEV MediumRec get_medium(const DeviceScene &sc, uint32_t i) { return sc.lds_media != kNone ? lds_row<MediumRec>(sc.lds_media, i) : const_row(sc.media, i); }
+DEV bool material_needs_uv(const DeviceScene &sc, uint32_t i)
+{
+    if (sc.lds_materials != kNone)
+        return *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_materials + i * (uint32_t)sizeof(MaterialRec) + (uint32_t)offsetof(MaterialRec, needs_uv)) != 0;
+    return sc.materials[i].needs_uv != 0;
+}
 
 template <class T>
 DEV const RT_CONST double *const_doubles(const T *p)
@@ -350,7 +360,10 @@ DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
         ph.n[k] += 1ull;                                                  \
     } while (0)
 struct PhaseSums {
-    unsigned long long t[16], l[16], n[16];  // 0 node, 1 leaf, 2 shade, 3 refill; inside the leaf phase: 4 group/instance, 5 medium, 6 primitive
+    // 0 node, 1 leaf, 2 shade, 3 refill; per-lane shares inside divergent code (scaled x1024): 4 group/instance, 5 medium,
+    // 6 primitive, 8 record+xforms, 9 box, 10 sub-BVH, 11 other geometry; wave level again: 16 box pass, 17 medium pass,
+    // 18 object pass, 19 primitive pass (kind-batched kernels), 20 hit record, 21 scatter, 22 next camera ray, 23 pixel done
+    unsigned long long t[24], l[24], n[24];
 };
 #define PH_ARG , PhaseSums &ph
 #define PH_PASS , ph
@@ -496,7 +509,8 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
 }
 
 // Composite leaf: instance chain and, for media, the stochastic volume hit (R/ConstantMedium.h:52-94).
-template <class T>
+// MED: what the caller knows about the leaf -- 1 a ConstantMedium, 0 not one, -1 look at the object record.
+template <class T, int MED = -1>
 DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
 {
 #if RT_PHASES
@@ -513,13 +527,18 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     }
 #endif
     // surfaces: one closest-hit query over [tmin, tmax]; media: two boundary queries (R/ConstantMedium.h:58-64)
-    const bool medium = T::MEDIA && o.medium != kNone;
+    const bool medium = T::MEDIA && (MED < 0 ? o.medium != kNone : MED == 1);
     double t1 = 0.0, t2 = 0.0;
     uint32_t pref = kNone;
+    MediumRec med{};
+    if (medium) med = get_medium(sc, o.medium);
     if (medium && o.geom_kind == GEOM_SINGLE && (o.first >> kRefShift) == REF_SPHERE) {
         // The usual boundary: one sphere.  Both queries of R/ConstantMedium.h:58-64 share oc, b, c and the
-        // discriminant (R/Sphere.h:28-34); only the root selection (:36-60) runs twice.
-        const SphereGeom g = sc.spheres[o.first & kRefIndexMask];
+        // discriminant (R/Sphere.h:28-34); only the root selection (:36-60) runs twice.  A sphere without transforms
+        // has its row repeated in the medium record (one table less to chase through).
+        SphereGeom g;
+        if (med.sphere != kNone) g = SphereGeom{med.cx, med.cy, med.cz, med.r2};
+        else g = sc.spheres[o.first & kRefIndexMask];
         const Vec oc = lr.o - mk(g.cx, g.cy, g.cz);
         const double a = dot(lr.d, lr.d);
         const double b = dot(oc, lr.d);
@@ -560,7 +579,7 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     // log(curand_uniform(..)) has a float argument: the float overload is selected on the reference's
     // toolchain; evaluated here as the correctly rounded fp32 log.
     float lg = (float)log((double)xorwow_uniform(rng));
-    double hit_dist = sc.media[o.medium].neg_inv_density * (double)lg;
+    double hit_dist = med.neg_inv_density * (double)lg;
     if (hit_dist > inside) return false;
     best.t = t1 + hit_dist / ray_len;
     best.ref = make_ref(REF_MEDIUM, o.medium);
@@ -568,10 +587,7 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     return true;
 }
 
-DEV bool is_medium_leaf(const DeviceScene &sc, uint32_t ref)
-{
-    return (ref >> kRefShift) == REF_OBJECT && get_object(sc, ref & kRefIndexMask).medium != kNone;
-}
+DEV bool is_medium_leaf(uint32_t ref) { return (ref >> kRefShift) == REF_MOBJECT; }  // tagged by the flattener
 
 template <class T>
 DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
@@ -590,10 +606,10 @@ DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
             PH_SUB_END(9);
             return found;
         }
-        if ((ref >> kRefShift) == REF_OBJECT) {
+        if ((ref >> kRefShift) == REF_OBJECT || (ref >> kRefShift) == REF_MOBJECT) {
             PH_SUB_BEGIN();
             const bool found = object_test<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng PH_PASS);
-            PH_SUB_END(is_medium_leaf(sc, ref) ? 5 : 4);
+            PH_SUB_END(is_medium_leaf(ref) ? 5 : 4);
             return found;
         }
     }
@@ -698,7 +714,7 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
     // span-1 nodes hold the same leaf twice (R/BvhNode.h:63-67).  Re-testing a surface with
     // tmax = its own t changes nothing; a medium draws again, so only media are re-tested.
     bool again = nb != na;
-    if constexpr (T::MEDIA) again = again || is_medium_leaf(sc, nb);
+    if constexpr (T::MEDIA) again = again || is_medium_leaf(nb);
     if constexpr (!T::COMPOSITE) {
         // The common bottom node of a sphere world: two moving-sphere rows (static spheres are stored as such rows too,
         // see unify_spheres).  Both rows are fetched together -- one round trip to L2 instead of two -- and tested in
@@ -733,6 +749,176 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
         }
     }
     w.state = next;
+}
+
+// Composite worlds: the leaf phase runs one KIND of leaf at a time.  A box, a medium, an instance and a plain primitive
+// are four different pieces of code; tested in one divergent pass the wave executes each of them with the few lanes
+// that happen to stand on that kind (measured on the Book-2 final scene: 12-16 of 64 lanes per pass).  So a parked
+// lane remembers which of its bottom node's two leaves is pending, the wave counts the pending leaves by kind, and a
+// kind is run when enough lanes wait for it (or the walkers have run out, or this is the last round before the next
+// look at the shading queue).  Each lane still meets its own leaves in the reference's order -- only when the wave
+// executes them changes -- so the RNG draws of media are consumed exactly as before.
+enum : uint32_t { LK_BOX = 0u, LK_MEDIUM = 1u, LK_OBJECT = 2u, LK_PRIM = 3u };
+constexpr uint32_t kWalkSecond = 0x40000000u;  // parked on the bottom node's SECOND leaf
+constexpr uint32_t kWalkNodeMask = 0x3FFFFFFFu;
+DEV uint32_t leaf_kind(uint32_t ref)
+{
+    const uint32_t tag = ref >> kRefShift;
+    return tag == REF_BOX ? LK_BOX : (tag == REF_MOBJECT ? LK_MEDIUM : (tag == REF_OBJECT ? LK_OBJECT : LK_PRIM));
+}
+// the pending leaf of a parked lane
+DEV uint32_t walk_pending_leaf(const NodeView &nv, uint32_t state)
+{
+    const uint32_t n = state & kWalkNodeMask, word = (state & kWalkSecond) ? 1u : 0u;
+    if (nv.in_lds) return lds_node_u32(nv.n, word, n);
+    return word ? nv.global[n].b : nv.global[n].a;
+}
+
+template <class T, uint32_t K>
+DEV bool leaf_test_kind(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
+{
+    if constexpr (K == LK_BOX) {
+        double t;
+        uint32_t face = kNone;
+        const bool found = box_closest(sc, get_box(sc, ref & kRefIndexMask), r, tmin, tmax, t, face);
+        if (found) {
+            best.t = t;
+            best.ref = face;
+            best.obj = kNone;
+        }
+        return found;
+    } else if constexpr (K == LK_MEDIUM) {
+        return object_test<T, 1>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng PH_PASS);
+    } else if constexpr (K == LK_OBJECT) {
+        return object_test<T, 0>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng PH_PASS);
+    } else {
+        double t;
+        const bool found = prim_test(sc, ref, r, a, tmin, tmax, t);
+        if (found) {
+            best.t = t;
+            best.ref = ref;
+            best.obj = kNone;
+        }
+        return found;
+    }
+}
+
+// One pass over the lanes whose pending leaf `ref` is of kind K: test it; if the node's other leaf is due (span-1 nodes
+// hold the same leaf twice, R/BvhNode.h:63-67: only a medium is tested again, see walk_leaves) and is of the same kind
+// it is tested in the same pass, otherwise the lane stays parked on it until that kind's pass.
+template <class T, uint32_t K>
+DEV void walk_leaf_pass(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng,
+                        uint32_t ref PH_ARG, bool have_first = false, bool first_found = false, double first_t = 0.0,
+                        uint32_t first_ref = kNone)
+{
+    const uint32_t n = w.state & kWalkNodeMask;
+    uint32_t nb, next;
+    if (nv.in_lds) {
+        nb = lds_node_u32(nv.n, 1, n); next = lds_node_u32(nv.n, 2, n);
+    } else {
+        nb = nv.global[n].b; next = nv.global[n].escape;
+    }
+    bool second = (w.state & kWalkSecond) != 0;
+    for (int c = 0; c < 2; c++) {  // one inlined copy of the test
+        bool found;
+        if (c == 0 && have_first) {  // the wave has already answered this one together (walk_object_pass)
+            found = first_found;
+            if (found) {
+                best.t = first_t;
+                best.ref = first_ref;
+                best.obj = ref & kRefIndexMask;
+            }
+        } else {
+            found = leaf_test_kind<T, K>(sc, ref, r, w.a, tmin, w.closest, best, rng PH_PASS);
+        }
+        if (found) {
+            w.any = true;
+            w.closest = best.t;
+        }
+        bool again = !second && nb != ref;
+        if constexpr (T::MEDIA) again = again || (!second && is_medium_leaf(nb));
+        if (!again) {
+            w.state = next;
+            break;
+        }
+        if (leaf_kind(nb) != K) {
+            w.state |= kWalkSecond;
+            break;
+        }
+        second = true;
+        ref = nb;
+    }
+}
+
+// The LK_OBJECT pass.  A large group of static spheres behind an instance (the Book-2 final scene's 1000-sphere
+// cluster) is not walked lane by lane through its sub-BVH in global memory -- a handful of lanes chasing ~50 dependent
+// L2 loads each while the other sixty wait -- but scanned by the whole wave, one parked ray at a time: lane l tests
+// spheres l, l + 64, ... of the group in object space and a wave-wide minimum over (t, index) picks the hit.  Spheres
+// draw no random numbers and the reference's list scan keeps the smallest acceptable root (lowest index on ties), so the
+// result is the one HittableList::Hit returns (R/HittableList.h:39-57; the same argument as scan_cooperative's).
+// Everything else of this kind (small groups, boxes behind transforms, ...) takes the per-lane test.
+DEV double bcast(double x, int src_lane);
+DEV void wave_min(double &t, uint32_t &k);
+template <class T>
+DEV void walk_object_pass(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng,
+                          uint32_t pending, bool mine, uint32_t lane PH_ARG)
+{
+    ObjectRec o{};
+    Ray lr = r;
+    o.coop_first = kNone;
+    if (mine) {
+        o = get_object(sc, pending & kRefIndexMask);
+        if (o.coop_first != kNone) lr = to_object_space(sc, o, r);
+    }
+    const bool coop = mine && o.coop_first != kNone;
+    bool found = false;
+    double found_t = 0.0;
+    uint32_t found_ref = kNone;
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        Ray q;
+        q.o = mk(bcast(lr.o.x, src), bcast(lr.o.y, src), bcast(lr.o.z, src));
+        q.d = mk(bcast(lr.d.x, src), bcast(lr.d.y, src), bcast(lr.d.z, src));
+        const double tmax = bcast(w.closest, src);
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)o.coop_first, src);
+        const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)o.count, src);
+        const double a = dot(q.d, q.d);
+        double bt = tmax;
+        uint32_t bk = kNone;
+        for (uint32_t base = 0; base < count; base += 256u) {
+            double b[4], c[4], disc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {  // four independent rows in flight per lane
+                uint32_t k = base + 64u * u + lane;
+                k = k < count ? k : count - 1u;  // stays inside the group's rows
+                const SphereGeom g = sc.spheres[first + k];
+                Vec oc = q.o - mk(g.cx, g.cy, g.cz);
+                b[u] = dot(oc, q.d);
+                c[u] = dot(oc, oc) - g.r2;
+                disc[u] = b[u] * b[u] - a * c[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = base + 64u * u + lane;
+                if (k < count && disc[u] > 0.0 && !(tmin >= 0.0 && b[u] > 0.0 && c[u] > 0.0)) {  // see sphere_test
+                    double t;
+                    if (sphere_roots(b[u], disc[u], a, tmin, bt, t)) {
+                        bt = t;
+                        bk = k;
+                    }
+                }
+            }
+        }
+        wave_min(bt, bk);
+        if ((int)lane == src) {
+            found = bk != kNone;
+            found_t = bt;
+            found_ref = make_ref(REF_SPHERE, first + bk);
+        }
+    }
+    if (mine) walk_leaf_pass<T, LK_OBJECT>(sc, nv, r, tmin, w, best, rng, pending PH_PASS, coop, found, found_t, found_ref);
 }
 
 // HittableList world (R/HittableList.h:39-57): the item index is wave-uniform, so the primitive rows
@@ -1086,6 +1272,83 @@ DEV void scan_grouped(const SphereView &sv, uint32_t lane, unsigned long long to
     }
 }
 
+// The same grouped scan for a BVH world of spheres / unit-time moving spheres (config C3), for thin waves once the pixel
+// queue has run dry.  A pixel's samples are one sequential chain, so a frame ends with a few long pixels (glass: up to
+// max_depth rays per sample); walked, each of their rays costs ~36 dependent node visits with most of the wave idle.
+// Scanned, the L live rays are dealt to groups of 64 / m lanes, every lane tests its share of ALL leaves (seven coalesced
+// plane reads per row) and one reduction per group picks the hit -- the same hit as the walk's: no leaf draws random
+// numbers, so the walk returns the closest acceptable root over all leaves (the reference's BVH = list invariant, Docs
+// 2-3 BVH :733,:772), ties going to the lower leaf index here.  Centre and roots are computed exactly as prim_test does.
+DEV void scan_grouped_ms(const DeviceScene &sc, uint32_t lane, unsigned long long todo, const Ray &ray, double tmin, double tmax,
+                         HitInfo &best, bool &hit)
+{
+    const uint32_t n = sc.n_world_items, np = sc.ms_padded;
+    const double *__restrict__ pl = sc.ms_planes;
+    const int L = __popcll(todo);
+    int log2m = 0;
+    while ((1 << log2m) < L) log2m++;
+    const int log2g = 6 - log2m;
+    const uint32_t g = 1u << log2g;
+    const uint32_t q = lane >> log2g, s = lane & (g - 1u);  // my ray slot and my place in its group
+    int owner = (int)lane;
+    {
+        unsigned long long m = todo;
+        for (int r = 0; r < L; r++) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            owner = q == (uint32_t)r ? src : owner;
+        }
+    }
+    Ray r;
+    r.o = mk(lane_read(ray.o.x, owner), lane_read(ray.o.y, owner), lane_read(ray.o.z, owner));
+    r.d = mk(lane_read(ray.d.x, owner), lane_read(ray.d.y, owner), lane_read(ray.d.z, owner));
+    r.tm = lane_read(ray.tm, owner);
+    const double a = dot(r.d, r.d);
+    double bt = tmax;
+    uint32_t bk = kNone;
+    for (uint32_t base = 0; base < np; base += 4u * g) {
+        double b[4], c[4], disc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t k = base + g * u + s;
+            k = k < np ? k : np - 1u;  // keeps the address inside the planes
+            const Vec c0 = mk(pl[k], pl[np + k], pl[2u * np + k]);
+            const Vec dc = mk(pl[3u * np + k], pl[4u * np + k], pl[5u * np + k]);
+            const Vec centre = c0 + r.tm * dc;  // msphere_center with unit time (a static sphere: dc = 0)
+            Vec oc = r.o - centre;
+            b[u] = dot(oc, r.d);
+            c[u] = dot(oc, oc) - pl[6u * np + k];
+            disc[u] = b[u] * b[u] - a * c[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t k = base + g * u + s;
+            if (k < n && disc[u] > 0.0 && !(tmin >= 0.0 && b[u] > 0.0 && c[u] > 0.0)) {  // see sphere_test
+                double t;
+                if (sphere_roots(b[u], disc[u], a, tmin, bt, t)) {
+                    bt = t;
+                    bk = k;
+                }
+            }
+        }
+    }
+    if (log2g >= 1) min_step<0xB1, 0xf>(bt, bk);   // quad_perm [1,0,3,2]
+    if (log2g >= 2) min_step<0x4E, 0xf>(bt, bk);   // quad_perm [2,3,0,1]
+    if (log2g >= 3) min_step<0x141, 0xf>(bt, bk);  // row_half_mirror
+    if (log2g >= 4) min_step<0x140, 0xf>(bt, bk);  // row_mirror
+    if (log2g >= 5) min_with_lane(bt, bk, (int)lane ^ 16);
+    if (log2g >= 6) min_with_lane(bt, bk, (int)lane ^ 32);
+    const int rank = __popcll(todo & ((1ull << lane) - 1ull));
+    const double rt = lane_read(bt, rank << log2g);
+    const uint32_t rk = (uint32_t)lane_read((int)bk, rank << log2g);
+    if ((todo >> lane) & 1ull) {
+        hit = rk != kNone;
+        best.t = rt;
+        best.ref = hit ? sc.world_items[rk] : kNone;
+        best.obj = kNone;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // hit record, built once per bounce from (t, primitive)
 // ------------------------------------------------------------------------------------------------
@@ -1116,7 +1379,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
             s.p = at(r, h.t);
             s.n = mk(1, 0, 0);
             s.front = true;
-            s.mat = sc.media[idx].phase_mat;
+            s.mat = get_medium(sc, idx).phase_mat;
             return s;
         }
     }
@@ -1134,7 +1397,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
         s.mat = sc.quad_mat[idx];
         face(s, lr, mk(q.nx, q.ny, q.nz));
         if constexpr (T::RICH) {
-            if (sc.materials[s.mat].needs_uv) {
+            if (material_needs_uv(sc, s.mat)) {
                 Vec ph = s.p - mk(q.qx, q.qy, q.qz);
                 Vec w = mk(q.wx, q.wy, q.wz);
                 s.u = dot(w, cross(ph, mk(q.vx, q.vy, q.vz)));
@@ -1156,7 +1419,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
         face(s, lr, on);
         s.mat = aux.mat;
         if constexpr (T::RICH) {
-            if (sc.materials[s.mat].needs_uv) sphere_uv(on, s.u, s.v);
+            if (material_needs_uv(sc, s.mat)) sphere_uv(on, s.u, s.v);
         }
     }
     if constexpr (T::COMPOSITE) {
@@ -1201,11 +1464,42 @@ DEV double perlin_noise(const PerlinRec *pn, Vec p)  // R/Perlin.h:38-60,120-139
     return accum;
 }
 
-DEV double perlin_turb(const PerlinRec *pn, Vec p, int depth)  // R/Perlin.h:63-78
+// The same from a table staged in LDS (layout of PerlinRec at byte offset `off`).  The global version above walks the
+// eight corners one dependent load chain after another (56 chains of two L2 round trips per marble lookup: one marble
+// lane held its whole wave for ~50k cycles); here the six permutation entries and the eight gradient rows are
+// independent LDS reads, summed in the reference's corner order.
+DEV double perlin_noise_lds(uint32_t off, Vec p)  // R/Perlin.h:38-60,120-139
+{
+    const double *vec = reinterpret_cast<const double *>(lds_raw + off);
+    const int32_t *perm = reinterpret_cast<const int32_t *>(lds_raw + off + 256u * 3u * (uint32_t)sizeof(double));
+    double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    double uu = u * u * (3.0 - 2.0 * u), vv = v * v * (3.0 - 2.0 * v), ww = w * w * (3.0 - 2.0 * w);
+    const int px[2] = {perm[i & 255], perm[(i + 1) & 255]};
+    const int py[2] = {perm[256 + (j & 255)], perm[256 + ((j + 1) & 255)]};
+    const int pz[2] = {perm[512 + (k & 255)], perm[512 + ((k + 1) & 255)]};
+    double accum = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int idx = px[a] ^ py[b] ^ pz[c];
+                Vec g = mk(vec[idx * 3 + 0], vec[idx * 3 + 1], vec[idx * 3 + 2]);
+                Vec wv = mk(u - a, v - b, w - c);
+                accum += (a * uu + (1 - a) * (1 - uu)) * (b * vv + (1 - b) * (1 - vv)) * (c * ww + (1 - c) * (1 - ww)) * dot(g, wv);
+            }
+    return accum;
+}
+
+DEV double perlin_turb(const DeviceScene &sc, uint32_t table, Vec p, int depth)  // R/Perlin.h:63-78
 {
     double accum = 0.0, weight = 1.0;
+    const bool in_lds = sc.lds_perlin != kNone;
     for (int i = 0; i < depth; i++) {
-        accum += weight * perlin_noise(pn, p);
+        accum += weight * (in_lds ? perlin_noise_lds(sc.lds_perlin + table * (uint32_t)sizeof(PerlinRec), p) : perlin_noise(sc.perlin + table, p));
         weight *= 0.5;
         p = 2.0 * p;
     }
@@ -1236,26 +1530,48 @@ DEV Vec texture_value(const DeviceScene &sc, uint32_t ti, double u, double v, Ve
             return mk(cs * px[0], cs * px[1], cs * px[2]);
         }
         if (t.kind == TEX_NOISE) {  // R/Texture.h:159-165: marble
-            double sv = 1.0 + sin(t.s * p.z + 10.0 * perlin_turb(sc.perlin + t.a, p, 7));
+            double sv = 1.0 + sin(t.s * p.z + 10.0 * perlin_turb(sc, t.a, p, 7));
             return sv * mk(0.5, 0.5, 0.5);
         }
     }
     return mk(t.r, t.g, t.b);  // TEX_SOLID, R/Texture.h:48-51
 }
 
+// One material row, read field by field from wherever the table lives: the LDS copy (small tables, launcher's choice)
+// or the global table.  Which one is wave-uniform, so each read is one scalar branch and one load.
+struct MatView {
+    const MaterialRec *global;
+    uint32_t lds_off;  // byte offset of the row in LDS, or kNone
+    DEV double f64(uint32_t off) const
+    {
+        if (lds_off != kNone) return *reinterpret_cast<const double *>(lds_raw + lds_off + off);
+        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(global) + off);
+    }
+    DEV uint32_t u32(uint32_t off) const
+    {
+        if (lds_off != kNone) return *reinterpret_cast<const uint32_t *>(lds_raw + lds_off + off);
+        return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(global) + off);
+    }
+    DEV Vec vec(uint32_t off) const { return mk(f64(off), f64(off + 8u), f64(off + 16u)); }
+};
+#define MAT_OFF(field) ((uint32_t)offsetof(MaterialRec, field))
+DEV MatView material_view(const DeviceScene &sc, uint32_t i)
+{
+    return MatView{sc.materials + i, sc.lds_materials != kNone ? sc.lds_materials + i * (uint32_t)sizeof(MaterialRec) : kNone};
+}
+
 // Texture of a material: host-resolved solid / checker-of-solids without touching the texture table.
 template <class T>
-DEV Vec material_texture(const DeviceScene &sc, const MaterialRec *m, uint32_t tex_inline, double u, double v, Vec p)
+DEV Vec material_texture(const DeviceScene &sc, const MatView &m, uint32_t tex_inline, double u, double v, Vec p)
 {
-    if (tex_inline == 1) return mk(m->even[0], m->even[1], m->even[2]);
+    if (tex_inline == 1) return m.vec(MAT_OFF(even));
     if (tex_inline == 2) {  // R/Texture.h:70-81
-        const double inv_scale = m->inv_scale;
+        const double inv_scale = m.f64(MAT_OFF(inv_scale));
         int xi = (int)floor(inv_scale * p.x), yi = (int)floor(inv_scale * p.y), zi = (int)floor(inv_scale * p.z);
         bool even = ((xi + yi + zi) % 2) == 0;
-        const double *c = even ? m->even : m->odd;
-        return mk(c[0], c[1], c[2]);
+        return m.vec(even ? MAT_OFF(even) : MAT_OFF(odd));
     }
-    if constexpr (T::RICH) return texture_value<T>(sc, m->tex, u, v, p);
+    if constexpr (T::RICH) return texture_value<T>(sc, m.u32(MAT_OFF(tex)), u, v, p);
     return mk(0.0, 0.0, 0.0);  // unreachable: scenes with table-walking textures run the RICH instantiation
 }
 
@@ -1290,8 +1606,8 @@ template <class T>
 DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughput, Vec &accumulated, Xorwow &rng)
 {
     // only the fields a material kind needs are loaded (the row is 112 bytes)
-    const MaterialRec *mp = sc.materials + s.mat;
-    struct { uint32_t kind, tex_inline; } m = {mp->kind, mp->tex_inline};
+    const MatView mp = material_view(sc, s.mat);
+    struct { uint32_t kind, tex_inline; } m = {mp.u32(MAT_OFF(kind)), mp.u32(MAT_OFF(tex_inline))};
     Vec atten;
     Ray out;
     out.o = s.p;
@@ -1312,14 +1628,14 @@ DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughpu
     }
     case MAT_METAL: {  // R/Metal.h:18-30
         Vec refl = reflect(ud, s.n);
-        out.d = refl + mp->p * rs;
-        atten = mk(mp->r, mp->g, mp->b);
+        out.d = refl + mp.f64(MAT_OFF(p)) * rs;
+        atten = mp.vec(MAT_OFF(r));
         if (!(dot(out.d, s.n) > 0.0)) return false;
         break;
     }
     case MAT_DIELECTRIC: {  // R/Dielectric.h:18-68
         atten = mk(1.0, 1.0, 1.0);
-        const double ior = mp->p;
+        const double ior = mp.f64(MAT_OFF(p));
         double ratio = s.front ? (1.0 / ior) : ior;
         double ct = fmin(dot(-ud, s.n), 1.0);
         double st = sqrt(1.0 - ct * ct);
@@ -1435,7 +1751,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         stage(sc.lds_boxes, sc.boxes, sc.n_boxes * (uint32_t)sizeof(BoxRec));
         stage(sc.lds_objects, sc.objects, sc.n_objects * (uint32_t)sizeof(ObjectRec));
         stage(sc.lds_xforms, sc.xforms, sc.n_xforms * (uint32_t)sizeof(Xform));
-        if (sc.lds_quad_aa != kNone) __syncthreads();  // all four are staged together or not at all
+        stage(sc.lds_media, sc.media, sc.n_media * (uint32_t)sizeof(MediumRec));
+        stage(sc.lds_materials, sc.materials, sc.n_materials * (uint32_t)sizeof(MaterialRec));
+        if constexpr (T::RICH) stage(sc.lds_perlin, sc.perlin, sc.n_perlin * (uint32_t)sizeof(PerlinRec));
+        __syncthreads();  // uniform: every thread of the block gets here
     }
     SphereView sv{};
     if constexpr (T::WORLD == 2) {
@@ -1586,7 +1905,18 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 PH_END(1, (todo >> lane) & 1ull);
             }
         }
-        if constexpr (T::WORLD == 0) {
+        bool thin = false;
+        if constexpr (T::WORLD == 0 && !T::COMPOSITE) {
+            // Frame tail of a sphere world: the queue is dry and few lanes are left -- scan instead of walking (scan_grouped_ms).
+            thin = exhausted && sc.ms_planes != nullptr && __popcll(live) < a.coop_threshold;
+            if (thin) {
+                PH_BEGIN();
+                scan_grouped_ms(sc, lane, live, ray, 0.001, DBL_MAX, h, hit);
+                walk.state = kNone;  // a walk in progress is dropped: the scan has covered every leaf
+                PH_END(1, active);
+            }
+        }
+        if constexpr (T::WORLD == 0) if (!thin) {
             // Traversal burst: every walking lane advances up to kBurst nodes.  Lanes whose walk is complete
             // wait for shading; they are shaded once enough of them have gathered (or nobody is walking any
             // more), then start their next ray and rejoin the walkers.
@@ -1620,7 +1950,38 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                         PH_END(0, mover);
                     }
                 }
-                {
+                if constexpr (T::BATCH) {
+                    const bool at_leaf = walk_parked(walk.state);
+                    if (__any(at_leaf)) {
+                        const uint32_t pending = at_leaf ? walk_pending_leaf(nv, walk.state) : kNone;
+                        const uint32_t kind = leaf_kind(pending);
+                        // everything is served in the last round before shading is looked at again, and when nobody walks
+                        const bool serve_all = round + 1 == kRoundsComposite || !__any(walk_moving(walk.state));
+#define RT_LEAF_PASS(K, SLOT)                                                                                          \
+                        {                                                                                              \
+                            const bool mine = at_leaf && kind == (K);                                                  \
+                            const int waiting = __popcll(__ballot(mine));                                              \
+                            if (waiting > 0 && (serve_all || waiting >= a.leaf_batch)) {                               \
+                                PH_BEGIN();                                                                            \
+                                if (mine) walk_leaf_pass<T, (K)>(sc, nv, ray, 0.001, walk, walk_best, rng, pending PH_PASS); \
+                                PH_END(SLOT, mine);                                                                    \
+                            }                                                                                          \
+                        }
+                        RT_LEAF_PASS(LK_BOX, 16)
+                        if constexpr (T::MEDIA) RT_LEAF_PASS(LK_MEDIUM, 17)
+                        {  // instances and groups: the whole wave takes part (walk_object_pass)
+                            const bool mine = at_leaf && kind == LK_OBJECT;
+                            const int waiting = __popcll(__ballot(mine));
+                            if (waiting > 0 && (serve_all || waiting >= a.object_batch)) {
+                                PH_BEGIN();
+                                walk_object_pass<T>(sc, nv, ray, 0.001, walk, walk_best, rng, pending, mine, lane PH_PASS);
+                                PH_END(18, mine);
+                            }
+                        }
+                        RT_LEAF_PASS(LK_PRIM, 19)
+#undef RT_LEAF_PASS
+                    }
+                } else {
                     const bool at_leaf = walk_parked(walk.state);
                     PH_BEGIN();
                     if (at_leaf) {
@@ -1654,10 +2015,33 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 accumulated = accumulated + throughput * load3c(((const RT_CONST CameraRec *)(uintptr_t)cam)->bg);
                 path_ends = true;
             } else {
+#if RT_PHASES
+                const unsigned long long ph_a = __builtin_readcyclecounter();
+#endif
                 Surface s = make_surface<T>(sc, ray, h);
+#if RT_PHASES
+                asm volatile("" ::"v"(s.p.x), "v"(s.n.z), "v"(s.mat));
+                const unsigned long long ph_b = __builtin_readcyclecounter();
+                ph.t[20] += ph_b - ph_a;
+                ph.l[20] += (unsigned long long)__popcll(__ballot(true));
+                ph.n[20] += 1ull;
+#endif
                 path_ends = !shade<T>(sc, s, ray, throughput, accumulated, rng);
+#if RT_PHASES
+                asm volatile("" ::"v"(ray.d.x), "v"(throughput.x));
+                ph.t[21] += __builtin_readcyclecounter() - ph_b;
+                ph.l[21] += (unsigned long long)__popcll(__ballot(true));
+                ph.n[21] += 1ull;
+#endif
                 if (!path_ends && ++depth >= a.max_depth) path_ends = true;  // R/kernel.cu:71,97
             }
+#if RT_PHASES
+            const unsigned long long ph_c = __builtin_readcyclecounter();
+            if (path_ends && sample + 1 < a.spp) {
+                ph.l[22] += (unsigned long long)__popcll(__ballot(true));
+                ph.n[22] += 1ull;
+            }
+#endif
             if (path_ends) {  // R/kernel.cu:143: col += RayColor(...)
                 col = col + accumulated;
                 if (++sample < a.spp) {
@@ -1689,6 +2073,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                     active = false;
                 }
             }
+#if RT_PHASES
+            asm volatile("" ::"v"(ray.d.x), "v"(col.x));
+            ph.t[22] += __builtin_readcyclecounter() - ph_c;  // next camera ray or pixel done (booked together)
+#endif
             if constexpr (T::WORLD == 0) {
                 if (active) walk_begin(walk, ray, DBL_MAX);
             }
@@ -1702,7 +2090,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
 #endif
     }
 #if RT_PHASES
-    for (int k = 4; k < 16; k++) {
+    for (int k = 4; k < 12; k++) {
         for (int off = 32; off > 0; off >>= 1) {
             ph.t[k] += __shfl_down(ph.t[k], off, 64);
             ph.l[k] += __shfl_down(ph.l[k], off, 64);
@@ -1713,10 +2101,10 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         ph.n[k] >>= 10;
     }
     if (lane == 0) {
-        for (int k = 0; k < 16; k++) {
-            atomicAdd(a.ray_counter + 16 + k, ph.t[k]);
-            atomicAdd(a.ray_counter + 32 + k, ph.l[k]);
-            atomicAdd(a.ray_counter + 48 + k, ph.n[k]);
+        for (int k = 0; k < 24; k++) {
+            atomicAdd(a.ray_counter + 32 + k, ph.t[k]);
+            atomicAdd(a.ray_counter + 64 + k, ph.l[k]);
+            atomicAdd(a.ray_counter + 96 + k, ph.n[k]);
         }
         atomicAdd(a.ray_counter + 7, __builtin_readcyclecounter() - ph_start);
     }
@@ -1828,7 +2216,7 @@ using TBvhMedia = Traits<0, true, false, 3, true>;                      // + Con
 #ifndef RT_WAVES_DEEP
 #define RT_WAVES_DEEP 3
 #endif
-using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP>;
+using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP, true, true>;
 // List scans over primitives / instances without media or table-walking textures.  Also the BVH worlds of small
 // scenes: for up to 16 leaves within a cost budget (FlatScene::scan_cost) a scan of all of them in the tree's leaf order -- every lane on the same leaf, rows
 // through uniform loads, no node visits, no phases -- beats walking the tree (Cornell box: 8 leaves, 7 nodes).  Without
@@ -1851,23 +2239,28 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             lds = need;
             a.lds_nodes = 1;
         }
-        if (T::COMPOSITE && a.lds_nodes) {
-            // the leaf-test tables of a small scene ride along (Cornell box: 2 KB)
-            const size_t b_quads = (size_t)sc.n_quads * sizeof(AAQuad), b_boxes = (size_t)sc.n_boxes * sizeof(BoxRec);
-            const size_t b_objects = (size_t)sc.n_objects * sizeof(ObjectRec), b_xforms = (size_t)sc.n_xforms * sizeof(Xform);
-            const size_t small = b_quads + b_boxes + b_objects + b_xforms;
+        if (T::COMPOSITE) {
+            // Small tables ride along behind the node rows, each on its own merits: the records a leaf test or the shading
+            // chases through (object -> transforms -> medium; material rows; Perlin tables: a few KB even in the Book-2
+            // final scene) and, where they fit as well, the quad / box rows (Cornell box: 2 KB).
+            const size_t budget = 52 * 1024;  // three workgroups per CU
             size_t off = (lds + 15) & ~(size_t)15;
-            if (small <= 16 * 1024 && off + small + 64 <= 60 * 1024) {
-                sc.lds_quad_aa = (uint32_t)off;
-                off += (b_quads + 15) & ~(size_t)15;
-                sc.lds_boxes = (uint32_t)off;
-                off += (b_boxes + 15) & ~(size_t)15;
-                sc.lds_objects = (uint32_t)off;
-                off += (b_objects + 15) & ~(size_t)15;
-                sc.lds_xforms = (uint32_t)off;
-                off += (b_xforms + 15) & ~(size_t)15;
-                lds = off;
+            auto place = [&](uint32_t &slot, size_t bytes, size_t cap) {
+                if (bytes == 0 || bytes > cap || off + bytes + 64 > budget) return;
+                slot = (uint32_t)off;
+                off += (bytes + 15) & ~(size_t)15;
+            };
+            place(sc.lds_objects, (size_t)sc.n_objects * sizeof(ObjectRec), 4096);
+            place(sc.lds_xforms, (size_t)sc.n_xforms * sizeof(Xform), 4096);
+            place(sc.lds_media, (size_t)sc.n_media * sizeof(MediumRec), 2048);
+            place(sc.lds_materials, (size_t)sc.n_materials * sizeof(MaterialRec), 4096);
+            if (T::RICH) place(sc.lds_perlin, (size_t)sc.n_perlin * sizeof(PerlinRec), 2 * sizeof(PerlinRec));
+            const size_t b_quads = (size_t)sc.n_quads * sizeof(AAQuad), b_boxes = (size_t)sc.n_boxes * sizeof(BoxRec);
+            if (b_quads + b_boxes <= 16 * 1024 && off + b_quads + b_boxes + 96 <= budget) {
+                place(sc.lds_quad_aa, b_quads, 16 * 1024);
+                place(sc.lds_boxes, b_boxes, 16 * 1024);
             }
+            lds = off;
         }
     } else if (T::WORLD == 2) {
         lds = 4 * kQueueCap * 64 * sizeof(uint16_t);

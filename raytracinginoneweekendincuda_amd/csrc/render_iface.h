@@ -36,6 +36,8 @@ struct RenderArgs {
     int32_t stripe_rows, rank, world_size;
     int32_t node_burst;     // composite BVH worlds: node visits between two leaf phases (set by the launcher)
     int32_t park_ratio;     // composite BVH worlds: the leaf phase starts once parked lanes outnumber moving ones by this factor
+    int32_t leaf_batch;     // composite BVH worlds: a kind of leaf is tested once this many lanes of the wave wait for it
+    int32_t object_batch;   // the same for instances / groups (their cooperative scan serves one ray at a time: a small batch is fine)
     int32_t lds_nodes;      // set by the launcher: BVH nodes are staged in LDS
     int32_t small_world;    // BVH worlds without media are scanned, not walked, up to this scan cost (and 16 leaves)
     int32_t always_walk;    // BVH worlds: walk the tree even where a scan of all leaves would be used (small scenes)

@@ -382,8 +382,9 @@ struct Flattener {
 
         ObjectRec obj{};
         obj.medium = kNone;
+        obj.coop_first = kNone;
         if (h->kind == HKind::Medium) {
-            f.media.push_back({h->neg_inv_density, h->material - 1, 0});
+            f.media.push_back({h->neg_inv_density, h->material - 1, kNone, 0.0, 0.0, 0.0, 0.0});
             obj.medium = (uint32_t)f.media.size() - 1;
             f.flags |= SCENE_HAS_MEDIA;
             h = &s.hittables[h->child - 1];
@@ -433,8 +434,11 @@ struct Flattener {
                 std::vector<uint32_t> objs = prims;
                 build_tree(&s, sub, objs, 0, (int)objs.size());
                 std::vector<uint32_t> ref_of(s.hittables.size() + 1, kNone);
+                const size_t spheres_before = f.spheres.size();
                 for (uint32_t hnd : objs)
                     if (ref_of[hnd] == kNone) ref_of[hnd] = add_primitive(s.hittables[hnd - 1]);
+                // all static spheres, each listed once: the rows just added are this group's, contiguously
+                if (all_s && f.spheres.size() - spheres_before == prims.size()) obj.coop_first = (uint32_t)spheres_before;
                 obj.geom_kind = GEOM_BVH;
                 obj.first = kNone;  // patched by emit_pending()
                 pending.push_back({(uint32_t)f.objects.size(), std::move(sub), std::move(ref_of)});
@@ -464,8 +468,14 @@ struct Flattener {
         }
         // a plain box needs nothing from the object record: the leaf points at the box itself
         if (obj.geom_kind == GEOM_BOX && obj.xf_count == 0 && obj.medium == kNone) return make_ref(REF_BOX, obj.first);
+        if (obj.medium != kNone && obj.geom_kind == GEOM_SINGLE && obj.xf_count == 0 && (obj.first >> kRefShift) == REF_SPHERE) {
+            const SphereGeom &g = f.spheres[obj.first & kRefIndexMask];
+            MediumRec &m = f.media[obj.medium];
+            m.sphere = obj.first & kRefIndexMask;
+            m.cx = g.cx; m.cy = g.cy; m.cz = g.cz; m.r2 = g.r2;
+        }
         f.objects.push_back(obj);
-        return make_ref(REF_OBJECT, (uint32_t)f.objects.size() - 1);
+        return make_ref(obj.medium != kNone ? REF_MOBJECT : REF_OBJECT, (uint32_t)f.objects.size() - 1);
     }
 
     void emit_pending()
@@ -659,6 +669,39 @@ int flatten_scene(SceneImpl &s)
         bool unit_time = !f.mspheres.empty();
         for (const MSphereGeom &m : f.mspheres) unit_time &= (m.t0 == 0.0 && m.dt == 1.0);
         if (unit_time) f.flags |= SCENE_MS_UNIT_TIME;
+        // A BVH world of nothing but spheres and unit-time moving spheres: thin waves scan all of them together instead of
+        // walking (order-independent: no leaf draws random numbers).  The planes hold the leaves in leaf order, a static
+        // sphere as a moving one that does not move (c0 + t * 0 = c0 exactly; not done when a centre component is -0.0).
+        bool all_ms = f.world_kind == WORLD_BVH && !f.world_items.empty() && (f.mspheres.empty() || unit_time) && f.quads.empty() &&
+                      f.objects.empty() && f.boxes.empty();
+        for (size_t k = 0; all_ms && k < f.world_items.size(); k++) {
+            const uint32_t tag = f.world_items[k] >> kRefShift, idx = f.world_items[k] & kRefIndexMask;
+            all_ms = tag == REF_MSPHERE || tag == REF_SPHERE;
+            if (tag == REF_SPHERE) {
+                const SphereGeom &g = f.spheres[idx];
+                all_ms = !(g.cx == 0.0 && std::signbit(g.cx)) && !(g.cy == 0.0 && std::signbit(g.cy)) && !(g.cz == 0.0 && std::signbit(g.cz));
+            }
+        }
+        if (all_ms) {
+            const size_t n = f.world_items.size(), np = (n + 63) & ~(size_t)63;
+            f.ms_padded = (uint32_t)np;
+            f.ms_planes.assign(7 * np, 0.0);
+            for (size_t k = 0; k < np; k++) {
+                const uint32_t ref = f.world_items[k < n ? k : 0];  // padding repeats leaf 0; the scan guards by index
+                double row[7];
+                if ((ref >> kRefShift) == REF_MSPHERE) {
+                    const MSphereGeom &g = f.mspheres[ref & kRefIndexMask];
+                    const double r7[7] = {g.c0x, g.c0y, g.c0z, g.dcx, g.dcy, g.dcz, g.r2};
+                    std::memcpy(row, r7, sizeof row);
+                } else {
+                    const SphereGeom &g = f.spheres[ref & kRefIndexMask];
+                    const double r7[7] = {g.cx, g.cy, g.cz, 0.0, 0.0, 0.0, g.r2};
+                    std::memcpy(row, r7, sizeof row);
+                }
+                for (int p2 = 0; p2 < 7; p2++) f.ms_planes[(size_t)p2 * np + k] = row[p2];
+            }
+            f.flags |= SCENE_WORLD_MSPHERES;
+        }
     }
     s.committed = true;
     return RT_OK;

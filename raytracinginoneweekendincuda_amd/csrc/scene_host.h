@@ -60,6 +60,8 @@ struct FlatScene {
     std::vector<SphereGeom> spheres;
     std::vector<SphereAux> sphere_aux;
     std::vector<MSphereGeom> mspheres;
+    std::vector<double> ms_planes;       // SCENE_WORLD_MSPHERES: seven planes of ms_padded doubles (see DeviceScene)
+    uint32_t ms_padded = 0;
     std::vector<SphereAux> msphere_aux;
     std::vector<QuadGeom> quads;
     std::vector<AAQuad> quad_aa;

@@ -524,3 +524,23 @@ def test_rtow_executable_takes_the_earth_texture(earth, tmp_path):
     cyan, _ = rt.builtin_scene(9, 0, 64, 48).render(64, 48, 2, variant=0)
     rt.write_ppm(b, cyan)
     assert hashlib.md5(c.read_bytes()).hexdigest() == hashlib.md5(b.read_bytes()).hexdigest()
+
+
+@pytest.mark.parametrize("scene_id", [0, 11])
+@pytest.mark.parametrize("variant", [0])
+def test_thin_wave_scan_of_a_sphere_bvh_world_equals_the_walk(oracle, scene_id, variant):
+    """BVH worlds of spheres / moving spheres (config C3): once the pixel queue is dry, a wave with few live lanes stops
+    walking and scans every leaf cooperatively (scan_grouped_ms).  No leaf draws random numbers, so the closest hit is the
+    walk's: same frame bit for bit, same ray count -- with the switch forced on as early as possible (threshold 65), with
+    the default, and never (threshold 1); and the scanned frame equals the oracle's."""
+    w, h, spp = 96, 64, 6
+    s = rt.builtin_scene(scene_id, 0, w, h)
+    walk, st0 = s.render(w, h, spp, variant=variant, coop_threshold=1)
+    scan, st1 = s.render(w, h, spp, variant=variant, coop_threshold=65)
+    dflt, st2 = s.render(w, h, spp, variant=variant)
+    assert st0.kernel_kind == 0, "expected the primitive BVH instantiation"
+    assert st0.rays == st1.rays == st2.rays
+    assert np.array_equal(walk.view(np.uint64), scan.view(np.uint64))
+    assert np.array_equal(walk.view(np.uint64), dflt.view(np.uint64))
+    want = oracle.render(scene_id, 0, w, h, spp)
+    assert np.array_equal(scan.view(np.uint64), want.view(np.uint64))

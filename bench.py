@@ -130,7 +130,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", default="fast", choices=["strict", "fast"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "strict", "fast"],
+                    help="auto = the fast build (FMA contraction) where its frame stays within the parity tolerance of the oracle "
+                         "at the benchmark's own spp (C2, C3, C4: >= 99.98 %% of pixels within 1e-5), the strict build for C5, where "
+                         "5000 samples per pixel through media give a contracted comparison a chance to flip in every pixel")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N GPUs: weak = N x the rows of the base frame (default), strong = the base frame striped over the ranks")
@@ -168,6 +171,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
+    if args.variant == "auto":
+        args.variant = "strict" if args.workload == "c5" else "fast"
     scene_id, world_kind, W, H0, spp, desc = wl
     if args.spp:
         spp = args.spp

@@ -151,6 +151,10 @@ typedef struct rt_render_params {
     int32_t overdue_rays_per_sample; /* tuning: a pixel past this many rays/sample advances in extra cooperative passes (0 or <0 = never, the default) */
     int32_t shade_batch;          /* tuning: BVH kernels shade once this many lanes finished traversal (0 = default 16) */
     int32_t max_blocks_per_cu;    /* tuning: cap on resident 256-thread workgroups per CU (0 = as many as fit) */
+    int32_t pixels_per_wave;      /* sphere-list worlds: pixels a wave works on at a time, 1..64 (0 = chosen from the pixels this rank owns).
+                                     Fewer than 64 leaves lanes free to share each ray's scan (64 / pixels lanes per ray): the same frame,
+                                     a shorter chain per pixel -- what a small frame, or one rank's share of a frame, needs */
+    int32_t reserved0;
 } rt_render_params;
 
 #define RT_FLAG_KEEP_RNG_STATE 1u  /* do not re-seed: continue from the film's saved per-pixel state (progressive) */

@@ -12,7 +12,7 @@ class RenderParams(C.Structure):
         ("seed", C.c_uint64), ("stripe_rows", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
         ("variant", C.c_int32), ("device", C.c_int32), ("flags", C.c_int32), ("stream", C.c_void_p),
         ("coop_threshold", C.c_int32), ("overdue_rays_per_sample", C.c_int32),
-        ("shade_batch", C.c_int32), ("max_blocks_per_cu", C.c_int32),
+        ("shade_batch", C.c_int32), ("max_blocks_per_cu", C.c_int32), ("pixels_per_wave", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -221,9 +221,9 @@ class Scene:
 
     # ---- one-call render on one GPU ----
     def render(self, width, height, spp, max_depth=50, seed=1984, variant=0, device=0, flags=0, coop_threshold=0,
-               overdue=0, shade_batch=0, max_blocks_per_cu=0):
+               overdue=0, shade_batch=0, max_blocks_per_cu=0, pixels_per_wave=0):
         p = RenderParams(width, height, spp, max_depth, seed, 8, 0, 1, variant, device, flags, None, coop_threshold, overdue,
-                         shade_batch, max_blocks_per_cu)
+                         shade_batch, max_blocks_per_cu, pixels_per_wave, 0)
         frame = np.zeros((height, width, 3), dtype=np.float64)
         st = RenderStats()
         _check(lib().rt_render(self._p, C.byref(p), frame.ctypes.data_as(_lib.D3), C.byref(st)))
@@ -251,9 +251,10 @@ class Film:
             self._p = None
 
     def params(self, spp, max_depth=50, seed=1984, variant=0, flags=0, stream=None, coop_threshold=0, overdue=0,
-               shade_batch=0, max_blocks_per_cu=0):
+               shade_batch=0, max_blocks_per_cu=0, pixels_per_wave=0):
         return RenderParams(self.width, self.height, spp, max_depth, seed, self.stripe_rows, self.rank, self.world_size,
-                            variant, self.device, flags, stream, coop_threshold, overdue, shade_batch, max_blocks_per_cu)
+                            variant, self.device, flags, stream, coop_threshold, overdue, shade_batch, max_blocks_per_cu,
+                            pixels_per_wave, 0)
 
     def launch(self, scene, params):
         _check(lib().rt_render_launch(scene._p, self._p, C.byref(params)))

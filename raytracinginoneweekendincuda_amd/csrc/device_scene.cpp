@@ -164,6 +164,8 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.items, d.items);
     up(f.xforms, d.xforms);
     up(f.media, d.media);
+    up(f.tree_nodes, d.tree_nodes);
+    up(f.tree_items, d.tree_items);
     up(f.nodes, d.nodes);
     up(f.world_items, d.world_items);
     up(f.materials, d.materials);
@@ -334,6 +336,8 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.num_cus = f.num_cus;
     ra.shade_batch = p->shade_batch > 0 ? p->shade_batch : 16;
     ra.max_blocks_per_cu = p->max_blocks_per_cu;
+    ra.pixels_per_wave = p->pixels_per_wave > 0 && p->pixels_per_wave < 64 ? p->pixels_per_wave : 64;
+    if (const char *e = std::getenv("RTOW_PIXELS_PER_WAVE")) ra.pixels_per_wave = std::atoi(e);  // experiments only
     ra.boost_rounds = 8;
     if (const char *e = std::getenv("RTOW_BOOST")) ra.boost_rounds = std::atoi(e);  // experiments only
     ra.grid_blocks = 0;
@@ -377,9 +381,10 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     if (const char *e = std::getenv("RTOW_SMALL_WORLD")) ra.small_world = std::atoi(e);  // experiments only
     const DeviceScene &ds = s.device[f.device]->scene;
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
-    // BVH sphere worlds: a walked ray costs ~20 us of dependent node visits whatever the wave holds, a scanned one a tenth
-    // of that while the wave is at most half full (scan_grouped_ms), so the switch comes earlier than for list worlds
-    if (f.last_kernel.kind < 8 && p->coop_threshold <= 0) ra.coop_threshold = 33;
+    // BVH sphere worlds: thin waves may scan all leaves together instead of walking (scan_grouped_ms), but the planes
+    // come from L2 and a chip full of thin waves scanning is bound by L2 bandwidth: measured slower than walking at every
+    // threshold (C3: 1748 Msamples/s never, 1681 at 17, 1048 at 33).  Off unless asked for.
+    if (f.last_kernel.kind < 8 && p->coop_threshold <= 0) ra.coop_threshold = 0;
     // BVH worlds: heaviest tiles first.  A pixel's samples are one sequential chain, so the frame cannot end before
     // its longest pixel does (glass: up to max_depth rays per sample).  In row-major order those pixels start
     // wherever they happen to lie and the frame ends long after the queue has drained (C3: drained at 38 ms, last

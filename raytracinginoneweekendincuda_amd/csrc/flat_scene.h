@@ -18,6 +18,7 @@ enum : uint32_t {
     REF_MEDIUM = 4u,   // only in hit results: index into media
     REF_BOX = 5u,      // leaves only: index into boxes (a MakeBox box without transform or medium; its hits are REF_QUAD)
     REF_MOBJECT = 6u,  // leaves only: index into objects, for an object that is a ConstantMedium (its test draws random numbers)
+    REF_TREE = 7u,     // index into tree_nodes: a composite that does not fit ObjectRec, kept as the reference's own object tree
     REF_INNER = 14u,   // BVH node marker: children are the next node and the escape target
     REF_NONE = 15u
 };
@@ -71,6 +72,23 @@ struct ObjectRec {
 // its row is repeated here so that the medium test needs no further table: sphere = its index in spheres[], else kNone.
 struct MediumRec { double neg_inv_density; uint32_t phase_mat; uint32_t sphere; double cx, cy, cz, r2; };
 
+// General nesting.  The reference's wrappers take any Hittable* (R/Instance.h:31,74, R/ConstantMedium.h:32,39,
+// R/HittableList.h:21, R/BvhNode.h:50).  Whatever ObjectRec cannot express -- a medium under a transform or inside another
+// medium, lists / BVHs of composites inside an instance, a BvhNode inside a list -- stays a tree of these records and is
+// evaluated by an explicit-stack interpreter (render.hip tree_hit) that makes the reference's calls in the reference's order.
+// `chain` = the transforms the world ray has gone through when this node's Hit is called (outermost first, a private
+// contiguous run of xforms[]): the local ray is always recomputed from the world ray, never un-transformed.
+enum : uint32_t { TN_PRIM = 0u, TN_TRANSLATE = 1u, TN_ROTATE_Y = 2u, TN_MEDIUM = 3u, TN_LIST = 4u, TN_BVH = 5u };
+struct TreeNodeRec {
+    uint32_t kind;
+    uint32_t a;  // PRIM: primitive ref; TRANSLATE / ROTATE_Y / MEDIUM: child node; LIST: first entry of tree_items[]; BVH: root in nodes[]
+    uint32_t b;  // MEDIUM: index into media; LIST: number of children
+    uint32_t chain_first, chain_count;
+    uint32_t pad0, pad1, pad2;
+};
+constexpr uint32_t kTreeMaxDepth = 16;      // frames of the interpreter's stack (the reference's recursion is bounded by its 32 KiB stack)
+constexpr uint32_t kTreeObjBit = 0x80000000u;  // HitInfo::obj of a hit inside a tree: this bit | node whose chain applies
+
 // Threaded BVH node, preorder.  Inner node: a = b = REF_INNER marker, first child = this + 1.
 // Bottom node (span 1 or 2, R/BvhNode.h:63-72): a, b = leaf refs (a == b for span 1).
 struct BvhNodeRec { double xlo, xhi, ylo, yhi, zlo, zhi; uint32_t a, b, escape, pad; };
@@ -118,6 +136,8 @@ struct DeviceScene {
     const Xform *xforms;
     const MediumRec *media;
     const BvhNodeRec *nodes;
+    const TreeNodeRec *tree_nodes;
+    const uint32_t *tree_items;   // children of TN_LIST nodes (tree node indices)
     const uint32_t *world_items;  // WORLD_LIST: leaf refs in list order
     const MaterialRec *materials;
     const TextureRec *textures;
@@ -149,6 +169,7 @@ enum : uint32_t {
     SCENE_LIST_ALL_SPHERES = 2u,  // WORLD_LIST whose leaves are spheres 0..n-1 in order (config C2 fast path)
     SCENE_RICH_TEXTURES = 4u,     // some texture is an ImageTexture or NoiseTexture
     SCENE_MS_UNIT_TIME = 8u,      // every moving-sphere row has time0 = 0, time1 - time0 = 1: frac == ray time
+    SCENE_HAS_TREES = 32u,        // some leaf is a REF_TREE: rendered by the nested instantiations
     SCENE_WORLD_MSPHERES = 16u,   // WORLD_BVH of spheres / unit-time moving spheres only: ms_planes is filled
 };
 

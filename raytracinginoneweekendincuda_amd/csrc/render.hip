@@ -13,7 +13,13 @@
 // an image texture will read them.  Each of these is result-preserving: see DESIGN.md.
 //
 // This file is compiled twice: RT_STRICT=1 with -ffp-contract=off (no FMA; bit-comparable with the
-// CPU oracle) and RT_STRICT=0 with the default contraction (fast variant).
+// CPU oracle) and RT_STRICT=0 with the default contraction (fast variant) -- and each of those in two groups of
+// instantiations (RT_GROUP), because they want different code generation: group 0 (sphere-list and primitive-BVH
+// kernels, seeding, dispatch) with the compiler's defaults, group 1 (every kernel with composite leaves, media or table
+// textures) with machine-level loop-invariant code motion off.  There LICM hoists the libm polynomial coefficients and
+// other constants of rarely executed code (log, sin, acos, atan2) out of the main loop into ~100 VGPRs and the register
+// allocator then spills them: 520 B/lane of scratch in the deep general kernel, 80 B without (C5 +10 %); the tight
+// primitive walk loses 5-7 % the same way, hence the split.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -27,6 +33,9 @@
 #ifndef RT_STRICT
 #define RT_STRICT 1
 #endif
+#ifndef RT_GROUP
+#define RT_GROUP 0
+#endif
 
 namespace rtow {
 namespace {
@@ -38,8 +47,10 @@ namespace {
 //   COMPOSITE  instances / boxes / lists / media may appear as leaves
 //   RICH       Perlin-noise or image textures may appear
 //   BATCH      BVH world with composite leaves: the leaf phase runs one kind of leaf at a time (deep trees, see walk_leaf_pass)
-template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false>
+//   NESTED     REF_TREE leaves may appear: composites kept as the reference's object tree (tree_hit)
+template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false, bool NESTED_ = false>
 struct Traits {
+    static constexpr bool NESTED = NESTED_ && COMPOSITE_;
     static constexpr bool BATCH = BATCH_ && COMPOSITE_ && WORLD_ == 0;
     static constexpr bool MEDIA = MEDIA_;  // ConstantMedium leaves may appear (needs COMPOSITE)
     static constexpr int MIN_WAVES = MIN_WAVES_;  // waves per SIMD the register allocator must leave room for
@@ -587,6 +598,204 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// General nesting: a composite kept as the reference's own object tree (flat_scene.h TreeNodeRec), evaluated by making
+// the reference's calls in the reference's order with an explicit stack -- Translate::Hit / RotateY::Hit
+// (R/Instance.h:41-56,116-150), HittableList::Hit (R/HittableList.h:39-57), ConstantMedium::Hit (R/ConstantMedium.h:52-94:
+// two boundary calls, one draw) and BvhNode::Hit (R/BvhNode.h:101-158, incl. BvhNode objects among the leaves, which its
+// loop walks as inner nodes).  The hit record is the kernel's usual (t, primitive, where): the point, normal and their
+// way back through the transforms are built once per bounce by make_surface from the winning node's chain.  A failed
+// call never touches the record (as in the reference, where every Hit writes only on success); a medium, whose boundary
+// calls write a record of their own, keeps the caller's in its frame.
+// ------------------------------------------------------------------------------------------------
+struct TreeFrame {
+    uint32_t node;
+    uint32_t step;     // LIST: next child; MEDIUM / transforms: 0, 1, 2; BVH: 0 visit, 1 after leaf a, 2 after leaf b
+    uint32_t cursor;   // BVH: threaded node
+    uint32_t any;
+    double tmin, tmax; // the interval this call was made with
+    double closest;    // LIST / BVH: closestSoFar;  MEDIUM: t of the first boundary hit
+    HitInfo saved;     // MEDIUM: the caller's record
+};
+
+DEV Ray chain_ray(const DeviceScene &sc, uint32_t first, uint32_t count, const Ray &r)
+{
+    Ray lr = r;
+    for (uint32_t k = 0; k < count; k++) {
+        Xform x = get_xform(sc, first + k);
+        if (x.kind == XF_TRANSLATE) {
+            lr.o = lr.o - mk(x.a, x.b, x.c);
+        } else {
+            double st = x.a, ct = x.b;
+            lr.o = mk((ct * lr.o.x) - (st * lr.o.z), lr.o.y, (st * lr.o.x) + (ct * lr.o.z));
+            lr.d = mk((ct * lr.d.x) - (st * lr.d.z), lr.d.y, (st * lr.d.x) + (ct * lr.d.z));
+        }
+    }
+    return lr;
+}
+
+template <class T>
+DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmin0, double tmax0, HitInfo &best, Xorwow &rng)
+{
+    TreeFrame stack[kTreeMaxDepth];
+    int sp = 0;
+    stack[0] = TreeFrame{root, 0u, kNone, 0u, tmin0, tmax0, tmax0, HitInfo{0.0, kNone, kNone}};
+    bool ret = false;            // what the call that has just returned answered
+    uint32_t chain_first = kNone, chain_count = 0;  // the chain `lr` was computed for
+    Ray lr = r;
+    for (;;) {
+        TreeFrame &f = stack[sp];
+        const TreeNodeRec n = sc.tree_nodes[f.node];
+        if (n.chain_first != chain_first || n.chain_count != chain_count) {  // always from the world ray: same bits every time
+            lr = chain_ray(sc, n.chain_first, n.chain_count, r);
+            chain_first = n.chain_first;
+            chain_count = n.chain_count;
+        }
+        uint32_t call = kNone;   // child to call next, with [call_tmin, call_tmax]
+        double call_tmin = 0.0, call_tmax = 0.0;
+        bool done = false, answer = false;
+        switch (n.kind) {
+        case TN_PRIM: {
+            double t;
+            answer = prim_test(sc, n.a, lr, dot(lr.d, lr.d), f.tmin, f.tmax, t);
+            if (answer) {
+                best.t = t;
+                best.ref = n.a;
+                best.obj = kTreeObjBit | f.node;
+            }
+            done = true;
+            break;
+        }
+        case TN_TRANSLATE:
+        case TN_ROTATE_Y:
+            if (f.step == 0) {
+                f.step = 1;
+                call = n.a; call_tmin = f.tmin; call_tmax = f.tmax;
+            } else {
+                done = true;
+                answer = ret;
+            }
+            break;
+        case TN_LIST:
+            if (f.step > 0 && ret) {
+                f.any = 1;
+                f.closest = best.t;
+            }
+            if (f.step < n.b) {
+                call = sc.tree_items[n.a + f.step];
+                call_tmin = f.tmin; call_tmax = f.closest;
+                f.step++;
+            } else {
+                done = true;
+                answer = f.any != 0;
+            }
+            break;
+        case TN_MEDIUM: {
+            if (f.step == 0) {
+                f.saved = best;
+                f.step = 1;
+                call = n.a; call_tmin = -DBL_MAX; call_tmax = DBL_MAX;
+            } else if (f.step == 1) {
+                if (!ret) {
+                    best = f.saved;
+                    done = true;
+                } else {
+                    f.closest = best.t;  // rec1.T
+                    f.step = 2;
+                    call = n.a; call_tmin = f.closest + 0.0001; call_tmax = DBL_MAX;
+                }
+            } else {
+                double t1 = f.closest, t2 = best.t;
+                const bool second = ret;
+                best = f.saved;
+                done = true;
+                if (second) {
+                    if (t1 < f.tmin) t1 = f.tmin;
+                    if (t2 > f.tmax) t2 = f.tmax;
+                    if (t1 < t2) {
+                        if (t1 < 0.0) t1 = 0.0;
+                        const MediumRec med = get_medium(sc, n.b);
+                        const double ray_len = length(lr.d);
+                        const double inside = (t2 - t1) * ray_len;
+                        const float lg = (float)log((double)xorwow_uniform(rng));  // see object_test
+                        const double hit_dist = med.neg_inv_density * (double)lg;
+                        if (!(hit_dist > inside)) {
+                            best.t = t1 + hit_dist / ray_len;
+                            best.ref = make_ref(REF_MEDIUM, n.b);
+                            best.obj = kTreeObjBit | f.node;
+                            answer = true;
+                        }
+                    }
+                }
+            }
+            break;
+        }
+        default: {  // TN_BVH
+            if (f.cursor == kNone) f.cursor = n.a;  // first entry: the root of this BvhNode's threaded nodes
+            for (;;) {
+                const BvhNodeRec node = sc.nodes[f.cursor];
+                if (f.step == 0) {
+                    const Vec inv = mk(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
+                    if (!box_test(node.xlo, node.xhi, node.ylo, node.yhi, node.zlo, node.zhi, lr, inv, f.tmin, f.closest)) {
+                        if (node.escape == kNone) {
+                            done = true;
+                            answer = f.any != 0;
+                            break;
+                        }
+                        f.cursor = node.escape;
+                        continue;
+                    }
+                    f.step = 1;
+                    if ((node.a >> kRefShift) != REF_INNER) {
+                        call = node.a & kRefIndexMask; call_tmin = f.tmin; call_tmax = f.closest;
+                        break;
+                    }
+                    ret = false;
+                }
+                if (f.step == 1) {
+                    if ((node.a >> kRefShift) != REF_INNER && ret) {
+                        f.any = 1;
+                        f.closest = best.t;
+                    }
+                    f.step = 2;
+                    if ((node.b >> kRefShift) != REF_INNER) {
+                        call = node.b & kRefIndexMask; call_tmin = f.tmin; call_tmax = f.closest;
+                        break;
+                    }
+                    ret = false;
+                }
+                // step 2: both children have been dealt with
+                if ((node.b >> kRefShift) != REF_INNER && ret) {
+                    f.any = 1;
+                    f.closest = best.t;
+                }
+                f.step = 0;
+                const bool has_inner = (node.a >> kRefShift) == REF_INNER || (node.b >> kRefShift) == REF_INNER;
+                const uint32_t next = has_inner ? f.cursor + 1u : node.escape;
+                if (next == kNone) {
+                    done = true;
+                    answer = f.any != 0;
+                    break;
+                }
+                f.cursor = next;
+            }
+            break;
+        }
+        }
+        if (call != kNone) {
+            if (sp + 1 >= (int)kTreeMaxDepth) return false;  // cannot happen: rt_scene_commit refuses deeper trees
+            sp++;
+            stack[sp] = TreeFrame{call, 0u, kNone, 0u, call_tmin, call_tmax, call_tmax, HitInfo{0.0, kNone, kNone}};
+            ret = false;
+            continue;
+        }
+        // done: return `answer` to the caller
+        ret = answer;
+        if (sp == 0) return ret;
+        sp--;
+    }
+}
+
 DEV bool is_medium_leaf(uint32_t ref) { return (ref >> kRefShift) == REF_MOBJECT; }  // tagged by the flattener
 
 template <class T>
@@ -612,6 +821,9 @@ DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
             PH_SUB_END(is_medium_leaf(ref) ? 5 : 4);
             return found;
         }
+    }
+    if constexpr (T::NESTED) {
+        if ((ref >> kRefShift) == REF_TREE) return tree_hit<T>(sc, ref & kRefIndexMask, r, tmin, tmax, best, rng);
     }
     PH_SUB_BEGIN();
     double t;
@@ -1086,10 +1298,17 @@ DEV double bcast(double x, int src_lane)
 // Sphere table as seen by the cooperative scan: four SoA planes in LDS (consecutive lanes read consecutive
 // 8-byte words: conflict-free), or the global AoS table when it does not fit.
 struct SphereView {
-    const double *cx, *cy, *cz, *r2;  // LDS planes, padded to a multiple of 64 with unhittable spheres
+    // The LDS planes are addressed as byte offsets off the __shared__ symbol (plane(p, k)), never through pointers: a
+    // pointer that may be LDS or global makes the compiler emit flat loads (19 of them in this kernel before), which are
+    // slower than ds_read and tie up both wait counters.
+    uint32_t planes_off;  // byte offset of plane 0 (cx); planes of n_padded doubles: cx, cy, cz, r2
     const SphereGeom *global;
     uint32_t n, n_padded;
     bool in_lds;
+    DEV double plane(uint32_t p, uint32_t k) const
+    {
+        return reinterpret_cast<const double *>(lds_raw + planes_off)[p * n_padded + k];
+    }
 };
 
 // Wave-wide minimum of (t, k) pairs with DPP row operations (no LDS traffic); result valid in every lane.
@@ -1141,9 +1360,9 @@ DEV void scan_cooperative(const SphereView &sv, uint32_t lane, unsigned long lon
                     // rows past n_padded are never read: clamp keeps the address inside the planes
                     uint32_t k = base + 64u * u + lane;
                     k = k < sv.n_padded ? k : sv.n_padded - 1u;
-                    Vec oc = r.o - mk(sv.cx[k], sv.cy[k], sv.cz[k]);
+                    Vec oc = r.o - mk(sv.plane(0, k), sv.plane(1, k), sv.plane(2, k));
                     b[u] = dot(oc, r.d);
-                    c[u] = dot(oc, oc) - sv.r2[k];
+                    c[u] = dot(oc, oc) - sv.plane(3, k);
                     disc[u] = b[u] * b[u] - a * c[u];
                 }
 #pragma unroll
@@ -1236,9 +1455,9 @@ DEV void scan_grouped(const SphereView &sv, uint32_t lane, unsigned long long to
         for (int u = 0; u < 4; u++) {
             uint32_t k = base + g * u + s;
             k = k < sv.n_padded ? k : sv.n_padded - 1u;  // keeps the address inside the planes
-            Vec oc = r.o - mk(sv.cx[k], sv.cy[k], sv.cz[k]);
+            Vec oc = r.o - mk(sv.plane(0, k), sv.plane(1, k), sv.plane(2, k));
             b[u] = dot(oc, r.d);
-            c[u] = dot(oc, oc) - sv.r2[k];
+            c[u] = dot(oc, oc) - sv.plane(3, k);
             disc[u] = b[u] * b[u] - a * c[u];
         }
 #pragma unroll
@@ -1374,25 +1593,33 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
     s.u = 0.0;
     s.v = 0.0;
     uint32_t tag = h.ref >> kRefShift, idx = h.ref & kRefIndexMask;
-    if constexpr (T::MEDIA) {
-        if (tag == REF_MEDIUM) {  // R/ConstantMedium.h:86-91
-            s.p = at(r, h.t);
-            s.n = mk(1, 0, 0);
-            s.front = true;
-            s.mat = get_medium(sc, idx).phase_mat;
-            return s;
-        }
-    }
-    ObjectRec o{};
+    // the transforms between the world and the space the hit was found in (outermost first), if any
+    uint32_t xf_first = 0, xf_count = 0;
     Ray lr = r;
     if constexpr (T::COMPOSITE) {
         if (h.obj != kNone) {
-            o = get_object(sc, h.obj);
-            lr = to_object_space(sc, o, r);
+            if (T::NESTED && (h.obj & kTreeObjBit)) {  // inside a tree: the winning node's chain
+                const TreeNodeRec n = sc.tree_nodes[h.obj & ~kTreeObjBit];
+                xf_first = n.chain_first;
+                xf_count = n.chain_count;
+            } else if (tag != REF_MEDIUM) {
+                const ObjectRec o = get_object(sc, h.obj);
+                xf_first = o.xf_first;
+                xf_count = o.xf_count;
+            }
+            lr = chain_ray(sc, xf_first, xf_count, r);
         }
     }
-    s.p = at(lr, h.t);
+    bool is_medium = false;
+    if constexpr (T::MEDIA) is_medium = tag == REF_MEDIUM;
+    if (is_medium) {  // R/ConstantMedium.h:86-91
+        s.p = at(lr, h.t);
+        s.n = mk(1, 0, 0);
+        s.front = true;
+        s.mat = get_medium(sc, idx).phase_mat;
+    } else
     if (T::WORLD != 2 && tag == REF_QUAD) {  // R/Quad.h:86-96
+        s.p = at(lr, h.t);
         QuadGeom q = sc.quads[idx];
         s.mat = sc.quad_mat[idx];
         face(s, lr, mk(q.nx, q.ny, q.nz));
@@ -1405,6 +1632,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
             }
         }
     } else {  // R/Sphere.h:40-46
+        s.p = at(lr, h.t);
         Vec c;
         SphereAux aux;
         if (T::WORLD == 2 || tag == REF_SPHERE) {
@@ -1424,8 +1652,8 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
     }
     if constexpr (T::COMPOSITE) {
         if (h.obj != kNone) {  // back to world space, innermost transform first (R/Instance.h:53,137-147)
-            for (uint32_t k = o.xf_count; k-- > 0;) {
-                Xform x = get_xform(sc, o.xf_first + k);
+            for (uint32_t k = xf_count; k-- > 0;) {
+                Xform x = get_xform(sc, xf_first + k);
                 if (x.kind == XF_TRANSLATE) {
                     s.p = s.p + mk(x.a, x.b, x.c);
                 } else {
@@ -1764,13 +1992,13 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         sv.n_padded = (sc.n_spheres + 63u) & ~63u;
         sv.in_lds = a.lds_spheres != 0;
         if (sv.in_lds) {
-            double *planes = reinterpret_cast<double *>(lds_raw + 4 * kQueueCap * 64 * sizeof(uint16_t));
+            sv.planes_off = 4u * kQueueCap * 64u * (uint32_t)sizeof(uint16_t);
+            double *planes = reinterpret_cast<double *>(lds_raw + sv.planes_off);
             const uint32_t np = sv.n_padded;
             for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
                 SphereGeom g = sc.spheres[k < sv.n ? k : 0];
                 planes[k] = g.cx; planes[np + k] = g.cy; planes[2 * np + k] = g.cz; planes[3 * np + k] = g.r2;
             }
-            sv.cx = planes; sv.cy = planes + np; sv.cz = planes + 2 * (size_t)np; sv.r2 = planes + 3 * (size_t)np;
             __syncthreads();
         }
     }
@@ -1831,7 +2059,11 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         }
 
         if (!exhausted && !boost) {
-            const unsigned long long need = __ballot(!active);
+            unsigned long long need = __ballot(!active);
+            if constexpr (T::WORLD == 2) {
+                // pixels_per_wave < 64: only the first lanes take pixels; the others lend themselves to the grouped scan
+                if (a.pixels_per_wave < 64) need &= (1ull << a.pixels_per_wave) - 1ull;
+            }
             if (need) {
                 PH_BEGIN();
                 [[maybe_unused]] const bool ph_was_idle = !active;
@@ -1844,7 +2076,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 if (exhausted && lane == 0) atomicMin(a.ray_counter + 2, (unsigned long long)wall_clock64());
 #endif
                 const uint32_t slot = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (!active && slot < total_slots) {
+                if (((need >> lane) & 1ull) && slot < total_slots) {
                     // heaviest tiles first when the launcher has ranked them (see rt_render_launch); else row-major
                     const uint32_t w = slot & 63u;
                     const uint32_t tile = (RT_ORDER_ON && a.tile_order) ? a.tile_order[slot >> 6] : slot >> 6;
@@ -1894,7 +2126,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         bool hit = false;
         if constexpr (T::WORLD == 2) {
             if (boost) todo = overdue;
-            if (!boost && __popcll(live) >= a.coop_threshold) {
+            if (!boost && a.pixels_per_wave >= 64 && __popcll(live) >= a.coop_threshold) {
                 PH_BEGIN();
                 if (active) hit = scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h);
                 PH_END(0, active);
@@ -2122,7 +2354,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     if (lane == 0 && total) atomicAdd(a.ray_counter, total);
 }
 
-#if RT_STRICT
+#if RT_STRICT && RT_GROUP == 0
 // Rank the tiles by probed cost, heaviest first.  A pixel's samples are sequential (one RNG stream), so the frame can
 // never end before its longest pixel does: those pixels have to start first, not wherever row-major order puts them.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, uint32_t *order, uint32_t n)
@@ -2182,6 +2414,7 @@ hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, ui
 #define RT_CAT2(a, b) a##b
 #define RT_CAT(a, b) RT_CAT2(a, b)
 
+#if RT_GROUP == 0
 hipError_t RT_CAT(launch_seed_, RT_SUFFIX)(const SeedArgs &a, hipStream_t stream)
 {
     if (a.n_pixels == 0) return hipSuccess;
@@ -2189,6 +2422,7 @@ hipError_t RT_CAT(launch_seed_, RT_SUFFIX)(const SeedArgs &a, hipStream_t stream
     hipLaunchKernelGGL(seed_kernel<RT_STRICT>, grid, block, 0, stream, a);
     return hipGetLastError();
 }
+#endif
 
 namespace {
 #ifndef RT_WAVES_SPHERES
@@ -2222,6 +2456,11 @@ using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP, true, true>;
 // through uniform loads, no node visits, no phases -- beats walking the tree (Cornell box: 8 leaves, 7 nodes).  Without
 // media no leaf draws random numbers, so the closest hit is the one the walk finds (the reference's own BVH = list
 // invariant; `tests/test_parity_gpu.py::test_small_world_scan_equals_the_bvh_walk`).
+// General nesting (REF_TREE leaves, tree_hit): the general kernels plus the interpreter.  Its stack of 16 frames lives in
+// scratch -- the reference's own recursion needs a 32 KiB stack per thread (R/kernel.cu:599) -- so these instantiations
+// are only ever launched for scenes that nest objects beyond what ObjectRec expresses (none of the ten built-in scenes).
+using TBvhNested = Traits<0, true, true, 2, true, false, true>;
+using TListNested = Traits<1, true, true, 2, true, false, true>;
 using TListPrims = Traits<1, false, false, 3>;
 using TListInstances = Traits<1, true, false, 3, false>;
 
@@ -2277,7 +2516,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
         if (e != hipSuccess) return e;
         info->vgprs = attr.numRegs;
         info->lds_bytes = (int)(attr.sharedSizeBytes + lds);
-        info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0);
+        info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0) + (T::NESTED ? 32 : 0);
         return hipSuccess;
     }
     if (a.n_pixels == 0 || a.spp <= 0) return hipSuccess;
@@ -2299,26 +2538,47 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
     return hipGetLastError();
 }
 
+} // namespace
+
+// instantiations of group 1, by id (defined in the RT_GROUP == 1 translation unit)
+enum CompositeKernel { CK_LIST_PRIMS, CK_LIST_INSTANCES, CK_LIST_GENERAL, CK_LIST_NESTED, CK_BVH_INSTANCES, CK_BVH_MEDIA,
+                       CK_BVH_GENERAL, CK_BVH_GENERAL_DEEP, CK_BVH_NESTED };
+hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info);
+
+#if RT_GROUP == 1
+hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info)
+{
+    switch (which) {
+    case CK_LIST_PRIMS: return launch_one<TListPrims>(sc, a, stream, info);
+    case CK_LIST_INSTANCES: return launch_one<TListInstances>(sc, a, stream, info);
+    case CK_LIST_GENERAL: return launch_one<TListGeneral>(sc, a, stream, info);
+    case CK_LIST_NESTED: return launch_one<TListNested>(sc, a, stream, info);
+    case CK_BVH_INSTANCES: return launch_one<TBvhInstances>(sc, a, stream, info);
+    case CK_BVH_MEDIA: return launch_one<TBvhMedia>(sc, a, stream, info);
+    case CK_BVH_GENERAL: return launch_one<TBvhGeneral>(sc, a, stream, info);
+    case CK_BVH_GENERAL_DEEP: return launch_one<TBvhGeneralDeep>(sc, a, stream, info);
+    default: return launch_one<TBvhNested>(sc, a, stream, info);
+    }
+}
+#else
+namespace {
 hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info)
 {
+    auto composite_kernel = [&](int which) { return RT_CAT(launch_composite_, RT_SUFFIX)(which, sc, a, stream, info); };
     const bool composite = sc.n_objects != 0 || sc.n_boxes != 0;
     const bool rich = (sc.flags & SCENE_RICH_TEXTURES) != 0;
     if ((sc.flags & SCENE_LIST_ALL_SPHERES) && !rich && sc.n_spheres <= 65535u && !a.force_general)
         return launch_one<TSphereList>(sc, a, stream, info);
+    if (sc.flags & SCENE_HAS_TREES) return composite_kernel(sc.world_kind == WORLD_BVH ? CK_BVH_NESTED : CK_LIST_NESTED);
     const bool media = (sc.flags & SCENE_HAS_MEDIA) != 0;
     const bool scan_world = sc.world_kind == WORLD_LIST || (sc.n_world_items <= 16u && sc.scan_cost <= (uint32_t)a.small_world && !a.always_walk);
-    if (scan_world && !rich && !media && !a.force_general)
-        return composite ? launch_one<TListInstances>(sc, a, stream, info) : launch_one<TListPrims>(sc, a, stream, info);
+    if (scan_world && !rich && !media && !a.force_general) return composite_kernel(composite ? CK_LIST_INSTANCES : CK_LIST_PRIMS);
     if (sc.world_kind == WORLD_BVH) {
         if (!composite && !rich && !a.force_general) return launch_one<TBvhPrims>(sc, a, stream, info);
-        if (!rich && !a.force_general) {
-            if (!(sc.flags & SCENE_HAS_MEDIA)) return launch_one<TBvhInstances>(sc, a, stream, info);
-            return launch_one<TBvhMedia>(sc, a, stream, info);
-        }
-        if (sc.n_world_nodes > 64) return launch_one<TBvhGeneralDeep>(sc, a, stream, info);
-        return launch_one<TBvhGeneral>(sc, a, stream, info);
+        if (!rich && !a.force_general) return composite_kernel(media ? CK_BVH_MEDIA : CK_BVH_INSTANCES);
+        return composite_kernel(sc.n_world_nodes > 64 ? CK_BVH_GENERAL_DEEP : CK_BVH_GENERAL);
     }
-    return launch_one<TListGeneral>(sc, a, stream, info);
+    return composite_kernel(CK_LIST_GENERAL);
 }
 } // namespace
 
@@ -2331,5 +2591,6 @@ hipError_t RT_CAT(kernel_info_, RT_SUFFIX)(const DeviceScene &sc, const RenderAr
 {
     return dispatch(sc, a, nullptr, info);
 }
+#endif
 
 } // namespace rtow

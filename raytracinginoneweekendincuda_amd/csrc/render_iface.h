@@ -50,6 +50,7 @@ struct RenderArgs {
     int32_t boost_rounds;   // overdue-only cooperative passes inserted after each pixel-parallel pass
     int32_t grid_blocks;        // tuning: hard cap on the persistent grid (0 = none)
     int32_t max_blocks_per_cu;  // tuning: cap on resident workgroups per CU (0 = whatever fits)
+    int32_t pixels_per_wave;    // sphere-list kernel: at most this many lanes of a wave hold a pixel (64 = all of them)
     int32_t shade_batch;    // BVH kernels: shade once this many lanes have finished their walk
     uint32_t ray_budget;    // sphere-list kernel: a pixel past this many rays is finished cooperatively
 };

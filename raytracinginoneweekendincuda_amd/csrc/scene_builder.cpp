@@ -374,11 +374,129 @@ struct Flattener {
         return false;
     }
 
+    // ---- general nesting: what ObjectRec cannot express stays a tree (flat_scene.h TreeNodeRec) ----
+    bool only_primitives(uint32_t handle) const  // a (nested) list / BVH whose members are all primitives
+    {
+        const HostHittable &h = s.hittables[handle - 1];
+        if (is_primitive(h.kind)) return true;
+        if (h.kind != HKind::List && h.kind != HKind::Bvh) return false;
+        for (uint32_t c : h.items)
+            if (!only_primitives(c)) return false;
+        return true;
+    }
+    // [ConstantMedium] -> Translate / RotateY chain -> a primitive or a list / BVH of primitives: the ObjectRec form
+    bool fits_flat(uint32_t handle) const
+    {
+        const HostHittable *h = &s.hittables[handle - 1];
+        if (h->kind == HKind::Medium) h = &s.hittables[h->child - 1];
+        while (h->kind == HKind::Translate || h->kind == HKind::RotateY) h = &s.hittables[h->child - 1];
+        if (h->kind == HKind::Medium) return false;
+        return only_primitives((uint32_t)(h - s.hittables.data()) + 1);
+    }
+    uint32_t tree_depth_seen = 0;
+    // One node of the tree for `handle`, whose Hit is called with the ray transformed by `chain` (outermost first).
+    uint32_t lower_tree(uint32_t handle, const std::vector<Xform> &chain, uint32_t depth)
+    {
+        if (depth > tree_depth_seen) tree_depth_seen = depth;
+        const HostHittable &h = s.hittables[handle - 1];
+        TreeNodeRec rec{};
+        rec.chain_first = (uint32_t)f.xforms.size();
+        rec.chain_count = (uint32_t)chain.size();
+        f.xforms.insert(f.xforms.end(), chain.begin(), chain.end());
+        const uint32_t me = (uint32_t)f.tree_nodes.size();
+        f.tree_nodes.push_back(rec);
+        if (is_primitive(h.kind)) {
+            rec.kind = TN_PRIM;
+            rec.a = add_primitive(h);
+        } else if (h.kind == HKind::Translate || h.kind == HKind::RotateY) {
+            std::vector<Xform> inner = chain;
+            if (h.kind == HKind::Translate) inner.push_back({h.offset.x, h.offset.y, h.offset.z, XF_TRANSLATE, 0});
+            else inner.push_back({h.sin_t, h.cos_t, 0.0, XF_ROTATE_Y, 0});
+            rec.kind = h.kind == HKind::Translate ? TN_TRANSLATE : TN_ROTATE_Y;
+            rec.a = lower_tree(h.child, inner, depth + 1);
+        } else if (h.kind == HKind::Medium) {
+            f.media.push_back({h.neg_inv_density, h.material - 1, kNone, 0.0, 0.0, 0.0, 0.0});
+            f.flags |= SCENE_HAS_MEDIA;
+            rec.kind = TN_MEDIUM;
+            rec.b = (uint32_t)f.media.size() - 1;
+            rec.a = lower_tree(h.child, chain, depth + 1);
+        } else if (h.kind == HKind::List) {
+            rec.kind = TN_LIST;
+            std::vector<uint32_t> kids;
+            for (uint32_t c : h.items) kids.push_back(lower_tree(c, chain, depth + 1));
+            rec.a = (uint32_t)f.tree_items.size();
+            rec.b = (uint32_t)kids.size();
+            f.tree_items.insert(f.tree_items.end(), kids.begin(), kids.end());
+        } else {  // HKind::Bvh
+            rec.kind = TN_BVH;
+            rec.a = thread_tree_general(h, 0, kNone, chain, depth + 1);
+        }
+        f.tree_nodes[me] = rec;
+        return me;
+    }
+    // Threaded nodes of a BvhNode inside a tree.  Unlike the world's (thread_tree), a child may be a BvhNode OBJECT: the
+    // reference's loop cannot tell it from one of its own inner nodes (Hittable::IsBvhNode, R/BvhNode.h:124-143), so it is
+    // spliced in as an inner child -- a node may then hold one leaf and one inner child, and a span-1 node over a BvhNode
+    // object walks that object's tree twice.  a / b = REF_TREE | tree node for a leaf, the REF_INNER marker for an inner
+    // child; the inner children follow the node in order, the first one at n + 1.
+    uint32_t thread_tree_general(const HostHittable &bvh, int ti, uint32_t escape, const std::vector<Xform> &chain, uint32_t depth)
+    {
+        const auto &tn = bvh.tree[ti];
+        const uint32_t me = (uint32_t)f.nodes.size();
+        f.nodes.push_back({});
+        BvhNodeRec rec{};
+        rec.xlo = tn.box.lo[0]; rec.xhi = tn.box.hi[0];
+        rec.ylo = tn.box.lo[1]; rec.yhi = tn.box.hi[1];
+        rec.zlo = tn.box.lo[2]; rec.zhi = tn.box.hi[2];
+        rec.escape = escape;
+        // the two children, each an inner subtree (own tree node, or a BvhNode object) or a leaf
+        struct Kid { bool inner; const HostHittable *owner; int index; uint32_t leaf; } kid[2];
+        for (int c = 0; c < 2; c++) {
+            if (tn.left >= 0) {
+                kid[c] = {true, &bvh, c == 0 ? tn.left : tn.right, 0};
+            } else {
+                const uint32_t hnd = c == 0 ? tn.leaf_a : tn.leaf_b;
+                const HostHittable &obj = s.hittables[hnd - 1];
+                if (obj.kind == HKind::Bvh) kid[c] = {true, &obj, 0, 0};
+                else kid[c] = {false, nullptr, 0, hnd};
+            }
+        }
+        uint32_t refs[2];
+        for (int c = 0; c < 2; c++)
+            refs[c] = kid[c].inner ? make_ref(REF_INNER, 0) : make_ref(REF_TREE, lower_tree(kid[c].leaf, chain, depth));
+        rec.a = refs[0];
+        rec.b = refs[1];
+        f.nodes[me] = rec;
+        // inner children in order; the first one's walk escapes to the second one, the last one's to this node's escape
+        const int n_inner = (kid[0].inner ? 1 : 0) + (kid[1].inner ? 1 : 0);
+        int seen = 0;
+        size_t first_begin = 0, first_end = 0;
+        for (int c = 0; c < 2; c++) {
+            if (!kid[c].inner) continue;
+            seen++;
+            if (seen == 1 && n_inner == 2) {
+                first_begin = f.nodes.size();
+                thread_tree_general(*kid[c].owner, kid[c].index, kNone - 1 /* placeholder */, chain, depth);
+                first_end = f.nodes.size();
+            } else {
+                if (n_inner == 2)
+                    for (size_t k = first_begin; k < first_end; k++)
+                        if (f.nodes[k].escape == kNone - 1) f.nodes[k].escape = (uint32_t)f.nodes.size();
+                thread_tree_general(*kid[c].owner, kid[c].index, escape, chain, depth);
+            }
+        }
+        return me;
+    }
+
     // Lower one world leaf to a ref.
     uint32_t lower_leaf(uint32_t handle)
     {
         const HostHittable *h = &s.hittables[handle - 1];
         if (is_primitive(h->kind)) return add_primitive(*h, true);
+        if (!fits_flat(handle)) {
+            f.flags |= SCENE_HAS_TREES;
+            return make_ref(REF_TREE, lower_tree(handle, {}, 1));
+        }
 
         ObjectRec obj{};
         obj.medium = kNone;
@@ -401,10 +519,6 @@ struct Flattener {
                 f.xforms.push_back({h->sin_t, h->cos_t, 0.0, XF_ROTATE_Y, 0});
             obj.xf_count++;
             h = &s.hittables[h->child - 1];
-        }
-        if (obj.xf_count > 8) {
-            err = "unsupported nesting: more than 8 chained instance transforms";
-            return kNone;
         }
         if (h->kind == HKind::Medium) {
             err = "unsupported nesting: ConstantMedium inside an instance transform";
@@ -602,13 +716,17 @@ int flatten_scene(SceneImpl &s)
         f.world_kind = WORLD_LIST;  // a lone hittable as world behaves as a list of one
         leaves.push_back(s.world);
     }
-    for (uint32_t h : leaves) {
-        HKind k = s.hittables[h - 1].kind;
-        if (world.kind == HKind::List && (k == HKind::List)) {
-            // list inside the world list: keep as a composite leaf (boxes), handled by lower_leaf
+    // A BvhNode OBJECT among a BvhNode world's leaves is walked by the reference as part of the world's own tree
+    // (Hittable::IsBvhNode, R/BvhNode.h:124-143), not called as a leaf.  Over primitives only that makes no difference
+    // (it becomes a group leaf); over composites the order of the leaf calls -- hence of the media's random draws -- does,
+    // and the whole world is then kept as one tree (flat_scene.h TreeNodeRec, thread_tree_general).
+    if (world.kind == HKind::Bvh) {
+        bool nested_bvh = false;
+        for (uint32_t h : leaves) nested_bvh |= s.hittables[h - 1].kind == HKind::Bvh && !fl.fits_flat(h);
+        if (nested_bvh) {
+            f.world_kind = WORLD_LIST;
+            leaves.assign(1, s.world);
         }
-        if (k == HKind::Bvh && world.kind != HKind::Bvh)
-            return fail(RT_ERR_UNSUPPORTED, "unsupported nesting: BvhNode inside a list world");
     }
     if (f.world_kind == WORLD_BVH) {
         bool any_static = false, any_moving = false, negative_zero = false;
@@ -644,6 +762,9 @@ int flatten_scene(SceneImpl &s)
         if (all_spheres && f.spheres.size() == f.world_items.size()) f.flags |= SCENE_LIST_ALL_SPHERES;
     }
     fl.emit_pending();
+    if (fl.tree_depth_seen > kTreeMaxDepth)
+        return fail(RT_ERR_UNSUPPORTED, "object nesting deeper than " + std::to_string(kTreeMaxDepth) +
+                                            " levels (the interpreter's stack; the reference's recursion is bounded by its 32 KiB stack)");
     {
         // What testing every leaf once costs, in half sphere tests (sphere 2, quad 3, box 12, a transform chain +4): the
         // launcher scans a small BVH world instead of walking it when this stays under a budget.  Measured: 16 spheres
@@ -655,6 +776,7 @@ int flatten_scene(SceneImpl &s)
             if (tag == REF_SPHERE || tag == REF_MSPHERE) cost += 2;
             else if (tag == REF_QUAD) cost += 3;
             else if (tag == REF_BOX) cost += 12;
+            else if (tag == REF_TREE) cost += 1000;
             else {
                 const ObjectRec &o = f.objects[idx];
                 cost += o.xf_count ? 4 : 0;

@@ -53,17 +53,31 @@ def test_commit_requires_world_and_camera():
         raise AssertionError
 
 
-def test_unsupported_nesting_is_reported():
+def test_general_nesting_commits_and_only_absurd_depth_is_refused():
+    """The reference's wrappers take any Hittable*: a medium inside a medium, a medium under a transform, a BvhNode inside
+    a list all commit (kept as an object tree for the nested kernels).  What is refused is a nesting deeper than the
+    interpreter's stack -- the reference's own recursion is bounded too (32 KiB of stack per thread, R/kernel.cu:599)."""
     s = rt.Scene()
     m = s.Lambertian((0.5, 0.5, 0.5))
     inner = s.ConstantMedium(s.Sphere((0, 0, 0), 1.0, m), 0.1, (1, 1, 1))
     outer = s.ConstantMedium(inner, 0.1, (1, 1, 1))
-    s.SetWorld(s.HittableList([outer]))
+    moved = s.Translate(s.ConstantMedium(s.Sphere((3, 0, 0), 1.0, m), 0.2, (1, 1, 1)), (0, 1, 0))
+    tree = s.BvhNode([s.MakeBox((5, 0, 0), (6, 1, 1), m), s.ConstantMedium(s.Sphere((8, 0, 0), 1.0, m), 0.3, (1, 1, 1))])
+    s.SetWorld(s.HittableList([outer, moved, tree]))
     s.Camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0)
+    s.Commit()
+    assert s.info()["n_media"] == 4 and s.info()["n_leaves"] == 3
+
+    deep = rt.Scene()
+    obj = deep.ConstantMedium(deep.Sphere((0, 0, 0), 1.0, deep.Lambertian((0.5, 0.5, 0.5))), 0.1, (1, 1, 1))
+    for k in range(20):   # lists of one are frames of their own
+        obj = deep.HittableList([deep.Translate(obj, (0.1, 0, 0))])
+    deep.SetWorld(deep.HittableList([obj]))
+    deep.Camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 1.0, 0.0, 10.0)
     try:
-        s.Commit()
+        deep.Commit()
     except rt.RtowError as e:
-        assert "unsupported nesting" in str(e)
+        assert "nesting deeper" in str(e)
     else:
         raise AssertionError
 

@@ -4,7 +4,8 @@ The built-in scenes (ids 0..11) are transcribed twice, once per side; the scenes
 function of a scene object, and run against raytracinginoneweekendincuda_amd.Scene (C-ABI, include/rtow.h) and
 against conftest.OracleScene (oracle_c_* constructors of oracle/rtow_oracle.c).  They cover what no built-in scene
 pins: the duplicated span-1 BVH leaf holding a ConstantMedium (SURVEY Q7, R/BvhNode.h:63-67 + R/ConstantMedium.h:52-94),
-and quads in every axis pairing / boxes thin, far and instanced.
+quads in every axis pairing / boxes thin, far and instanced, and the reference's general object nesting
+(R/Instance.h:31-56,74-150, R/ConstantMedium.h:32-50, R/HittableList.h:21-57, R/BvhNode.h:50-90,124-143).
 """
 import numpy as np
 import pytest
@@ -114,3 +115,119 @@ def test_quad_zoo_matches_the_oracle(world_kind):
     paper-thin / instanced: the AAQuad and BoxRec shortcuts of flat_scene.h against R/Quad.h:52-99 evaluated in full
     by the oracle (not against the kernel's own general test)."""
     check(_quad_zoo(world_kind), w=96, h=64, spp=8)
+
+
+# ---- general nesting (R/Instance.h, R/ConstantMedium.h, R/HittableList.h, R/BvhNode.h take any Hittable*) ----
+def _room(s, items, cam_from=(0, 1.2, 6.5), cam_at=(0, 0.6, 0), vfov=50.0, bg=(0.55, 0.65, 0.9), world="bvh"):
+    floor = s.Quad((-30, -1, -30), (60, 0, 0), (0, 0, 60), s.Lambertian(s.CheckerTexture(0.8, s.SolidColor((0.2, 0.3, 0.1)),
+                                                                                         s.SolidColor((0.9, 0.9, 0.9)))))
+    items = list(items) + [floor]
+    s.SetWorld(s.BvhNode(items) if world == "bvh" else s.HittableList(items))
+    s.Camera(cam_from, cam_at, (0, 1, 0), vfov, W / H, 0.0, 10.0, 0.0, 1.0, bg)
+    s.Commit()
+
+
+NESTINGS = {}
+
+
+def nesting(fn):
+    NESTINGS[fn.__name__] = fn
+    return fn
+
+
+@nesting
+def medium_under_transforms(s, Rng):
+    """Translate(RotateY(ConstantMedium(box))) -- the reference's scene 8 has the medium OUTSIDE the instance; here it is inside."""
+    white = s.Lambertian((0.73, 0.73, 0.73))
+    fog = s.ConstantMedium(s.MakeBox((0, 0, 0), (1.6, 2.0, 1.6), white), 1.1, (0.9, 0.9, 0.9))
+    inst = s.Translate(s.RotateY(fog, 25.0), (-1.4, -1.0, -0.5))
+    ball = s.ConstantMedium(s.Sphere((0, 0, 0), 0.9, white), 2.0, (0.1, 0.2, 0.7))
+    inst2 = s.RotateY(s.Translate(ball, (1.7, 0.0, 0.4)), -40.0)
+    _room(s, [inst, inst2])
+
+
+@nesting
+def medium_in_medium(s, Rng):
+    """ConstantMedium whose boundary is a ConstantMedium (R/ConstantMedium.h:32: boundary is any Hittable*): the inner
+    medium's stochastic hit is the outer one's boundary query, twice per call."""
+    white = s.Lambertian((0.73, 0.73, 0.73))
+    inner = s.ConstantMedium(s.Sphere((0, 0.3, 0), 1.3, white), 3.0, (0.8, 0.3, 0.3))
+    outer = s.ConstantMedium(inner, 1.5, (0.2, 0.8, 0.3))
+    _room(s, [outer, s.Sphere((2.6, 0, -1), 1.0, s.Metal((0.8, 0.8, 0.8), 0.0))])
+
+
+@nesting
+def instance_of_composites(s, Rng):
+    """Translate(RotateY(HittableList[box, Translate(sphere), ConstantMedium(sphere)])): a list of non-primitives inside an instance."""
+    white, red = s.Lambertian((0.73, 0.73, 0.73)), s.Lambertian((0.65, 0.05, 0.05))
+    members = [s.MakeBox((-0.5, -1, -0.5), (0.5, 0.2, 0.5), white),
+               s.Translate(s.Sphere((0, 0, 0), 0.45, s.Dielectric(1.5)), (0.0, 0.7, 0.0)),
+               s.ConstantMedium(s.Sphere((1.3, -0.3, 0.2), 0.7, white), 2.5, (0.3, 0.3, 0.9)),
+               s.RotateY(s.MakeBox((-1.9, -1, -0.4), (-1.1, 0.6, 0.4), red), 30.0)]
+    group = s.Translate(s.RotateY(s.HittableList(members), 20.0), (0.2, 0.0, -0.8))
+    _room(s, [group, s.Sphere((-2.9, 0.0, -1.5), 1.0, s.Metal((0.7, 0.6, 0.5), 0.1))])
+
+
+@nesting
+def bvh_inside_a_list_world(s, Rng):
+    """HittableList world whose members include a BvhNode over primitives and a BvhNode over composites."""
+    rng = Rng(7, 3)
+    mats = [s.Lambertian((0.7, 0.3, 0.2)), s.Metal((0.8, 0.8, 0.9), 0.05), s.Dielectric(1.5), s.Lambertian((0.2, 0.5, 0.8))]
+    balls = []
+    for k in range(23):
+        x, y, z = -4 + 8 * rng.uniform(), -0.7 + 1.5 * rng.uniform(), -3 + 4 * rng.uniform()
+        balls.append(s.Sphere((x, y, z), 0.3, mats[k % 4]))
+    comps = [s.Translate(s.RotateY(s.MakeBox((0, 0, 0), (0.8, 1.4, 0.8), mats[0]), 15.0), (-3.2, -1.0, 1.2)),
+             s.ConstantMedium(s.Sphere((2.6, 0.2, 1.4), 0.8, mats[0]), 1.5, (0.9, 0.9, 0.9)),
+             s.MakeBox((0.2, -1.0, 1.6), (1.0, -0.2, 2.4), mats[3])]
+    _room(s, [s.BvhNode(balls), s.BvhNode(comps)], world="list")
+
+
+@nesting
+def instance_of_a_bvh_of_composites(s, Rng):
+    """RotateY(BvhNode[boxes, instanced boxes, a medium]): the sub-tree is walked in the reference's order inside the
+    instance, media leaves (incl. a span-1 one) drawing as they are met."""
+    white, green = s.Lambertian((0.73, 0.73, 0.73)), s.Lambertian((0.12, 0.45, 0.15))
+    members = [s.MakeBox((-2.4, -1, -0.4), (-1.6, 0.3, 0.4), white),
+               s.Translate(s.MakeBox((0, 0, 0), (0.7, 0.7, 0.7), green), (-0.9, -1.0, 0.3)),
+               s.ConstantMedium(s.MakeBox((0.3, -1.0, -0.5), (1.3, 0.5, 0.5), white), 2.0, (0.8, 0.8, 0.8)),
+               s.Sphere((2.1, -0.4, 0.0), 0.6, s.Dielectric(1.5)),
+               s.ConstantMedium(s.Sphere((3.4, -0.3, 0.2), 0.7, white), 1.2, (0.9, 0.4, 0.1))]
+    tree = s.BvhNode(members)
+    _room(s, [s.Translate(s.RotateY(tree, -12.0), (-0.4, 0.0, -0.6))])
+
+
+@nesting
+def many_chained_transforms(s, Rng):
+    """Eleven chained Translate / RotateY wrappers around one box (the reference recurses without a limit)."""
+    obj = s.MakeBox((-0.6, -0.6, -0.6), (0.6, 0.6, 0.6), s.Lambertian((0.8, 0.5, 0.2)))
+    for k in range(11):
+        obj = s.RotateY(obj, 7.0 + k) if k % 2 == 0 else s.Translate(obj, (0.11 * k, 0.02 * k, -0.05 * k))
+    _room(s, [obj, s.Sphere((-2.2, 0, 0), 1.0, s.Lambertian(s.NoiseTexture(3.0, Rng(1984, 0))))])
+
+
+@nesting
+def list_of_lists_world(s, Rng):
+    """A HittableList world holding HittableLists of mixed members, three levels deep, plus a lone medium."""
+    white = s.Lambertian((0.73, 0.73, 0.73))
+    inner = s.HittableList([s.Sphere((-1.5, -0.4, 0), 0.6, s.Metal((0.9, 0.6, 0.3), 0.3)),
+                            s.HittableList([s.Quad((-0.5, -1, -1), (1, 0, 0), (0, 1.6, 0), white),
+                                            s.ConstantMedium(s.Sphere((1.5, -0.2, 0.5), 0.8, white), 1.8, (0.4, 0.7, 0.9))])])
+    _room(s, [s.HittableList([inner, s.MakeBox((2.6, -1, -1), (3.4, 0.4, -0.2), white)])], world="list")
+
+
+@nesting
+def bvh_object_among_the_leaves_of_a_bvh_world(s, Rng):
+    """BvhNode world whose leaves include a BvhNode OBJECT over composites: the reference's loop walks it as part of the
+    world's own tree (IsBvhNode), leaf siblings first -- not as a leaf call.  (_room builds the BvhNode world.)"""
+    white = s.Lambertian((0.73, 0.73, 0.73))
+    inner = s.BvhNode([s.ConstantMedium(s.Sphere((-1.6, 0.0, 0.3), 0.8, white), 1.6, (0.8, 0.3, 0.2)),
+                       s.MakeBox((-0.4, -1.0, -0.5), (0.5, 0.4, 0.4), white),
+                       s.ConstantMedium(s.MakeBox((0.9, -1.0, -0.6), (1.9, 0.7, 0.5), white), 1.1, (0.2, 0.3, 0.8))])
+    _room(s, [inner, s.Sphere((3.0, 0.0, -0.5), 0.9, s.Metal((0.8, 0.8, 0.8), 0.05)),
+              s.ConstantMedium(s.Sphere((-3.2, 0.2, -0.8), 0.9, white), 0.9, (0.9, 0.9, 0.9))])
+
+
+@pytest.mark.parametrize("name", sorted(NESTINGS))
+def test_general_nesting_matches_the_oracle(name):
+    check(NESTINGS[name], spp=6, min_exact=0.97)

@@ -19,10 +19,11 @@ CASES = [
     (10, 0, 0.99), (10, 1, 0.99),    # C1 three spheres
     (11, 1, 0.99),                   # C2 random spheres, list world
     (0, 0, 0.99), (0, 1, 0.99),      # C3 random spheres + moving spheres + checker
-    (1, 0, 0.99), (2, 0, 0.95), (3, 0, 0.5), (4, 0, 1.0), (5, 0, 0.5),
+    # measured: scene 3 (marble: device sin) 0.960, scene 5 0.998, everything else 1.000 -- the floors sit a point or two below
+    (1, 0, 0.99), (2, 0, 0.98), (3, 0, 0.94), (4, 0, 1.0), (5, 0, 0.98),
     (6, 0, 1.0), (7, 0, 1.0), (7, 1, 1.0),   # C4 Cornell + instances
-    (8, 0, 0.9), (8, 1, 0.9),        # smoke
-    (9, 0, 0.5), (9, 1, 0.5),        # C5 final scene
+    (8, 0, 0.98), (8, 1, 0.98),      # smoke
+    (9, 0, 0.98), (9, 1, 0.98),      # C5 final scene
 ]
 
 
@@ -250,6 +251,10 @@ def test_cooperative_scan_equals_pixel_parallel_scan(scene_id, world_kind):
     assert np.array_equal(ref.view(np.uint64), allc.view(np.uint64))
     assert np.array_equal(ref.view(np.uint64), over.view(np.uint64))
     assert st0.rays == st1.rays == st2.rays
+    for ppw in (1, 8, 24):   # a wave holds this many pixels and 64 / ppw lanes share each ray's scan
+        few, st3 = _render(scene_id, world_kind, pixels_per_wave=ppw)
+        assert np.array_equal(ref.view(np.uint64), few.view(np.uint64)), ppw
+        assert st3.rays == st0.rays
 
 
 def _many_spheres(n):

@@ -164,6 +164,9 @@ typedef struct rt_render_params {
 #define RT_FLAG_FORCE_GENERAL 2u   /* tests: run the general kernel even where a specialised instantiation applies */
 #define RT_FLAG_ALWAYS_WALK 32u     /* small BVH worlds without media (up to 16 cheap leaves) are rendered by scanning all leaves in the tree's
                                       leaf order (same closest hit, no node visits); this flag walks the tree anyway */
+#define RT_FLAG_NO_PIXEL_CLASSES 64u /* sphere-list worlds: render every pixel in one launch (default: a rehearsal of the first samples finds the
+                                      few pixels with long ray chains, which a launch of their own renders with several lanes per ray beside
+                                      the launch of all the others; the image is the same either way) */
 #define RT_FLAG_ROW_MAJOR_TILES 16u /* BVH worlds: keep the pixel queue in row-major tile order (default: a short rehearsal ranks
                                       the 8x8 tiles by rays traced and the heaviest start first; the image is the same either way) */
 

@@ -108,6 +108,12 @@ struct FilmImpl {
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
     uint32_t *tile_cost = nullptr, *tile_order = nullptr;  // per 8x8 tile of this rank's rows: probed rays, and the tiles ranked by them
+    // sphere-list worlds, heavy / light pixels (allocated on first use): probed rays per pixel, the heavy pixels' list and
+    // count, every pixel's class; the heavy launch runs on its own stream beside the light one
+    uint32_t *pix_cost = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;
+    uint8_t *pix_class = nullptr;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux[2] = {nullptr, nullptr};
     uint32_t n_tiles = 0;
     unsigned long long *host_counters = nullptr;  // pinned mirror of ray_counter, filled by an async copy behind the render
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // begin, after seed, after render, after the counter copy
@@ -164,8 +170,10 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.items, d.items);
     up(f.xforms, d.xforms);
     up(f.media, d.media);
+    up(f.group_boxes, d.group_boxes);
     up(f.tree_nodes, d.tree_nodes);
     up(f.tree_items, d.tree_items);
+    up(f.tree_bvh, d.tree_bvh);
     up(f.nodes, d.nodes);
     up(f.world_items, d.world_items);
     up(f.materials, d.materials);
@@ -195,7 +203,8 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_media = (uint32_t)f.media.size();
     d.n_materials = (uint32_t)f.materials.size();
     d.n_perlin = (uint32_t)f.perlin.size();
-    d.lds_quad_aa = d.lds_boxes = d.lds_objects = d.lds_xforms = d.lds_media = d.lds_materials = d.lds_perlin = kNone;
+    d.n_group_boxes = (uint32_t)f.group_boxes.size();
+    d.lds_quad_aa = d.lds_boxes = d.lds_objects = d.lds_xforms = d.lds_media = d.lds_materials = d.lds_perlin = d.lds_spheres_tab = d.lds_group_boxes = kNone;
     d.flags = f.flags;
     s.device[device] = dt;
     return RT_OK;
@@ -261,6 +270,13 @@ void rt_film_destroy(rt_film *film)
     if (f->ray_counter) hipFree(f->ray_counter);
     if (f->tile_cost) hipFree(f->tile_cost);
     if (f->tile_order) hipFree(f->tile_order);
+    if (f->pix_cost) hipFree(f->pix_cost);
+    if (f->heavy_list) hipFree(f->heavy_list);
+    if (f->heavy_count) hipFree(f->heavy_count);
+    if (f->pix_class) hipFree(f->pix_class);
+    for (int k = 0; k < 2; k++)
+        if (f->ev_aux[k]) hipEventDestroy(f->ev_aux[k]);
+    if (f->aux_stream) hipStreamDestroy(f->aux_stream);
     if (f->host_counters) hipHostFree(f->host_counters);
     for (int k = 0; k < 4; k++)
         if (f->ev[k]) hipEventDestroy(f->ev[k]);
@@ -385,35 +401,83 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     // come from L2 and a chip full of thin waves scanning is bound by L2 bandwidth: measured slower than walking at every
     // threshold (C3: 1748 Msamples/s never, 1681 at 17, 1048 at 33).  Off unless asked for.
     if (f.last_kernel.kind < 8 && p->coop_threshold <= 0) ra.coop_threshold = 0;
-    // BVH worlds: heaviest tiles first.  A pixel's samples are one sequential chain, so the frame cannot end before
-    // its longest pixel does (glass: up to max_depth rays per sample).  In row-major order those pixels start
-    // wherever they happen to lie and the frame ends long after the queue has drained (C3: drained at 38 ms, last
-    // wave out at 99 ms).  A rehearsal of the first sample(s) of every pixel -- same RNG streams, nothing written but a
-    // ray count per 8x8 tile -- ranks the tiles; its cost is spp_probe / spp of the frame.  Not for the sphere-list
-    // kernel: there the cooperative scan already finishes a thin tail quickly, and heaviest-first measured slower.
-    {
-        const bool bvh_kernel = f.last_kernel.kind < 8;
-        bool rank_tiles = bvh_kernel && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 && !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
-        if (const char *e = std::getenv("RTOW_TILE_SORT")) rank_tiles = rank_tiles && std::atoi(e) != 0;  // experiments only
+    // A pixel's samples are one sequential chain (one RNG stream), so a frame cannot end before its longest pixel does
+    // (glass: up to max_depth rays per sample).  One rehearsal of the first samples of every pixel -- the same RNG streams,
+    // nothing written but ray counts, cost probe_spp / spp of the frame -- serves two schedulers:
+    //  * BVH worlds, heaviest tiles first: the 8x8 tiles are ranked by rays traced and the pixel queue hands them out in
+    //    that order (in row-major order C3's queue drained at 38 ms and the last wave left at 99 ms);
+    //  * sphere-list and primitive-BVH worlds, heavy and light pixels: the few pixels with long chains (0.4 % of C2's
+    //    trace more than 10 rays per sample, up to 41) are listed and rendered by a launch of their own, started first on
+    //    a second stream, in which a wave holds only a few pixels -- the lanes share each ray's scan (sphere list: a
+    //    third of the latency per ray at 1.8x the work), or simply have the wave to themselves (BVH walk) -- while the other
+    //    launch skips them.  C2 took 367 ms where its throughput alone needs ~310; 338 ms with the two launches.
+    // Every pixel is still rendered exactly once from its own stream: the frame is the same bit for bit
+    // (tests: ...tile_ranking..., ...heavy_and_light...; RT_FLAG_ROW_MAJOR_TILES / RT_FLAG_NO_PIXEL_CLASSES turn them off).
+    const bool bvh_kernel = f.last_kernel.kind < 8;
+    bool rank_tiles = bvh_kernel && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 && !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
+    if (const char *e = std::getenv("RTOW_TILE_SORT")) rank_tiles = rank_tiles && std::atoi(e) != 0;  // experiments only
+    const bool list_kernel = f.last_kernel.kind >= 16, prim_bvh_kernel = f.last_kernel.kind == 0;
+    bool split = (list_kernel || prim_bvh_kernel) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
+                 f.n_pixels >= 65536u && p->pixels_per_wave <= 0 && !std::getenv("RTOW_PIXELS_PER_WAVE");
+    if (const char *e = std::getenv("RTOW_PIXEL_CLASSES")) split = split && std::atoi(e) != 0;  // experiments only
+    if (prim_bvh_kernel && !std::getenv("RTOW_PIXEL_CLASSES")) split = false;  // BVH worlds: opt-in until measured
+    if (rank_tiles || split) {
+        int probe_spp = split ? 4 : p->samples_per_pixel / 100;
+        probe_spp = probe_spp < 1 ? 1 : (probe_spp > 8 ? 8 : probe_spp);
+        if (const char *e = std::getenv("RTOW_PROBE_SPP")) probe_spp = std::atoi(e);  // experiments only
+        if (probe_spp > p->samples_per_pixel) probe_spp = p->samples_per_pixel;
+        if (split && !f.pix_cost) {
+            HIP_TRY(hipMalloc((void **)&f.pix_cost, (size_t)f.n_pixels * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **)&f.heavy_list, (size_t)f.n_pixels * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **)&f.heavy_count, 64));
+            HIP_TRY(hipMalloc((void **)&f.pix_class, (size_t)f.n_pixels));
+            HIP_TRY(hipStreamCreateWithFlags(&f.aux_stream, hipStreamNonBlocking));
+            for (int k = 0; k < 2; k++) HIP_TRY(hipEventCreateWithFlags(&f.ev_aux[k], hipEventDisableTiming));
+        }
+        RenderArgs probe = ra;
+        probe.probe = 1;
+        probe.spp = probe_spp;
+        probe.accum = nullptr;
+        probe.spp_before = 0;
+        probe.tile_cost = rank_tiles ? f.tile_cost : nullptr;
+        probe.tile_order = nullptr;
+        probe.pix_cost = split ? f.pix_cost : nullptr;
+        if (rank_tiles) HIP_TRY(hipMemsetAsync(f.tile_cost, 0, f.n_tiles * sizeof(uint32_t), stream));
+        HIP_TRY(p->variant ? launch_render_fast(ds, probe, stream) : launch_render_strict(ds, probe, stream));
         if (rank_tiles) {
-            int probe_spp = p->samples_per_pixel / 100;
-            probe_spp = probe_spp < 1 ? 1 : (probe_spp > 8 ? 8 : probe_spp);
-            if (const char *e = std::getenv("RTOW_PROBE_SPP")) probe_spp = std::atoi(e);
-            RenderArgs probe = ra;
-            probe.probe = 1;
-            probe.spp = probe_spp;
-            probe.accum = nullptr;
-            probe.spp_before = 0;
-            probe.tile_cost = f.tile_cost;
-            probe.tile_order = nullptr;
-            HIP_TRY(hipMemsetAsync(f.tile_cost, 0, f.n_tiles * sizeof(uint32_t), stream));
-            HIP_TRY(p->variant ? launch_render_fast(ds, probe, stream) : launch_render_strict(ds, probe, stream));
             HIP_TRY(launch_tile_order(f.tile_cost, f.tile_order, f.n_tiles, stream));
-            HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, queue cursor
             ra.tile_order = f.tile_order;
+        }
+        HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, (light) queue cursor
+        if (split) {
+            int heavy_rays_per_sample = 10, heavy_ppw = list_kernel ? 4 : 16, heavy_blocks = f.num_cus, heavy_prio = list_kernel ? 0 : 2;
+            if (const char *e = std::getenv("RTOW_HEAVY_RAYS")) heavy_rays_per_sample = std::atoi(e);  // experiments only, all four
+            if (const char *e = std::getenv("RTOW_HEAVY_PPW")) heavy_ppw = std::atoi(e);
+            if (const char *e = std::getenv("RTOW_HEAVY_BLOCKS")) heavy_blocks = std::atoi(e);
+            if (const char *e = std::getenv("RTOW_HEAVY_PRIO")) heavy_prio = std::atoi(e);
+            HIP_TRY(hipMemsetAsync(f.heavy_count, 0, 64, stream));
+            HIP_TRY(launch_classify_pixels(f.pix_cost, f.n_pixels, (uint32_t)(heavy_rays_per_sample * probe_spp), f.pix_class,
+                                           f.heavy_list, f.heavy_count, stream));
+            HIP_TRY(hipMemsetAsync(f.ray_counter + 6, 0, sizeof(unsigned long long), stream));  // heavy queue cursor
+            HIP_TRY(hipEventRecord(f.ev_aux[0], stream));
+            HIP_TRY(hipStreamWaitEvent(f.aux_stream, f.ev_aux[0], 0));
+            RenderArgs heavy = ra;
+            heavy.tile_order = nullptr;
+            heavy.pixel_list = f.heavy_list;
+            heavy.pixel_list_count = f.heavy_count;
+            heavy.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
+            heavy.pixels_per_wave = heavy_ppw;
+            if (list_kernel) heavy.coop_threshold = 65;  // always the grouped scan
+            heavy.grid_blocks = heavy_blocks;
+            heavy.max_blocks_per_cu = 8;
+            heavy.wave_priority = heavy_prio;
+            HIP_TRY(p->variant ? launch_render_fast(ds, heavy, f.aux_stream) : launch_render_strict(ds, heavy, f.aux_stream));
+            HIP_TRY(hipEventRecord(f.ev_aux[1], f.aux_stream));
+            ra.pix_class = f.pix_class;
         }
     }
     HIP_TRY(p->variant ? launch_render_fast(ds, ra, stream) : launch_render_strict(ds, ra, stream));
+    if (split) HIP_TRY(hipStreamWaitEvent(stream, f.ev_aux[1], 0));
     HIP_TRY(hipEventRecord(f.ev[2], stream));
     // The counters come home on the film's own stream: a blocking hipMemcpy in rt_render_finish would wait for every
     // other film's frame as well and serialise frames that were launched to overlap.

@@ -66,8 +66,13 @@ struct ObjectRec {
     uint32_t medium;     // index into media or kNone
     uint32_t coop_first; // GEOM_BVH over static spheres only: their rows are spheres[coop_first .. coop_first + count), so a wave
                          // may scan them together instead of walking the sub-BVH lane by lane; kNone otherwise
-    uint32_t pad1;
+    uint32_t coop_boxes; // ... and group_boxes[coop_boxes + g] bounds rows 16 g .. 16 g + 15 of them (a cull for that scan)
 };
+// Bounding box of sixteen consecutive rows of a cooperative sphere group, padded outwards (a conservative cull: a ray
+// that could hit one of the sixteen always passes the slab test).  The rows are in the sub-BVH's leaf order, so
+// consecutive rows are neighbours in space.
+struct GroupBox { double lo[3], hi[3]; };
+constexpr uint32_t kCoopGroup = 16;
 // R/ConstantMedium.h:39-44.  When the boundary is a lone Sphere without transforms (both media of the Book-2 final scene),
 // its row is repeated here so that the medium test needs no further table: sphere = its index in spheres[], else kNone.
 struct MediumRec { double neg_inv_density; uint32_t phase_mat; uint32_t sphere; double cx, cy, cz, r2; };
@@ -81,7 +86,7 @@ struct MediumRec { double neg_inv_density; uint32_t phase_mat; uint32_t sphere; 
 enum : uint32_t { TN_PRIM = 0u, TN_TRANSLATE = 1u, TN_ROTATE_Y = 2u, TN_MEDIUM = 3u, TN_LIST = 4u, TN_BVH = 5u };
 struct TreeNodeRec {
     uint32_t kind;
-    uint32_t a;  // PRIM: primitive ref; TRANSLATE / ROTATE_Y / MEDIUM: child node; LIST: first entry of tree_items[]; BVH: root in nodes[]
+    uint32_t a;  // PRIM: primitive ref; TRANSLATE / ROTATE_Y / MEDIUM: child node; LIST: first entry of tree_items[]; BVH: root in tree_bvh[]
     uint32_t b;  // MEDIUM: index into media; LIST: number of children
     uint32_t chain_first, chain_count;
     uint32_t pad0, pad1, pad2;
@@ -135,9 +140,11 @@ struct DeviceScene {
     const uint32_t *items;        // GEOM_MIXED entries (prim refs)
     const Xform *xforms;
     const MediumRec *media;
+    const GroupBox *group_boxes;
     const BvhNodeRec *nodes;
     const TreeNodeRec *tree_nodes;
     const uint32_t *tree_items;   // children of TN_LIST nodes (tree node indices)
+    const BvhNodeRec *tree_bvh;   // threaded nodes of the BvhNodes inside trees (a table of their own: nodes[] starts with the world's)
     const uint32_t *world_items;  // WORLD_LIST: leaf refs in list order
     const MaterialRec *materials;
     const TextureRec *textures;
@@ -156,11 +163,11 @@ struct DeviceScene {
     uint32_t n_world_nodes;
     uint32_t scan_cost;      // what testing every world leaf once costs, in half sphere tests
     uint32_t n_spheres, n_mspheres, n_quads, n_objects, n_boxes, n_xforms;
-    uint32_t n_media, n_materials, n_perlin;
+    uint32_t n_media, n_materials, n_perlin, n_group_boxes;
     // Tables a leaf test or the shading chases through -- object record -> transforms -> box / quad rows, medium rows,
     // material rows, Perlin tables -- are staged in LDS behind the node rows where they fit.  Byte offsets into the
     // dynamic LDS block, set by the launcher per table; kNone = read the global table.
-    uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin;
+    uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin, lds_spheres_tab, lds_group_boxes;
     uint32_t flags;
 };
 

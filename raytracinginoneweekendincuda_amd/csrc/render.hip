@@ -48,8 +48,13 @@ namespace {
 //   RICH       Perlin-noise or image textures may appear
 //   BATCH      BVH world with composite leaves: the leaf phase runs one kind of leaf at a time (deep trees, see walk_leaf_pass)
 //   NESTED     REF_TREE leaves may appear: composites kept as the reference's object tree (tree_hit)
-template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false, bool NESTED_ = false>
+//   BLOCK      threads per workgroup.  256 (four waves) everywhere except the deep general kernel, which runs ONE workgroup of
+//              768 threads per CU -- three waves per SIMD as before, but one copy of the scene tables in the CU's 160 KB of LDS
+//              instead of three in 52 KB each: besides the node rows, the box rows and the sphere table fit as well
+template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false, bool NESTED_ = false,
+          int BLOCK_ = 256>
 struct Traits {
+    static constexpr int BLOCK = BLOCK_;
     static constexpr bool NESTED = NESTED_ && COMPOSITE_;
     static constexpr bool BATCH = BATCH_ && COMPOSITE_ && WORLD_ == 0;
     static constexpr bool MEDIA = MEDIA_;  // ConstantMedium leaves may appear (needs COMPOSITE)
@@ -135,6 +140,8 @@ DEV AAQuad get_quad_aa(const DeviceScene &sc, uint32_t i) { return sc.lds_quad_a
 DEV BoxRec get_box(const DeviceScene &sc, uint32_t i) { return sc.lds_boxes != kNone ? lds_row<BoxRec>(sc.lds_boxes, i) : const_row(sc.boxes, i); }
 DEV ObjectRec get_object(const DeviceScene &sc, uint32_t i) { return sc.lds_objects != kNone ? lds_row<ObjectRec>(sc.lds_objects, i) : const_row(sc.objects, i); }
 DEV Xform get_xform(const DeviceScene &sc, uint32_t i) { return sc.lds_xforms != kNone ? lds_row<Xform>(sc.lds_xforms, i) : const_row(sc.xforms, i); }
+DEV SphereGeom get_sphere(const DeviceScene &sc, uint32_t i) { return sc.lds_spheres_tab != kNone ? lds_row<SphereGeom>(sc.lds_spheres_tab, i) : sc.spheres[i]; }
+DEV GroupBox get_group_box(const DeviceScene &sc, uint32_t i) { return sc.lds_group_boxes != kNone ? lds_row<GroupBox>(sc.lds_group_boxes, i) : sc.group_boxes[i]; }
 DEV MediumRec get_medium(const DeviceScene &sc, uint32_t i) { return sc.lds_media != kNone ? lds_row<MediumRec>(sc.lds_media, i) : const_row(sc.media, i); }
 DEV bool material_needs_uv(const DeviceScene &sc, uint32_t i)
 {
@@ -346,7 +353,7 @@ DEV bool prim_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
     uint32_t idx = ref & kRefIndexMask;
     switch (ref >> kRefShift) {
     case REF_SPHERE: {
-        SphereGeom g = const_row(sc.spheres, idx);
+        SphereGeom g = sc.lds_spheres_tab != kNone ? lds_row<SphereGeom>(sc.lds_spheres_tab, idx) : const_row(sc.spheres, idx);
         return sphere_test(r.o - mk(g.cx, g.cy, g.cz), r.d, a, g.r2, tmin, tmax, t);
     }
     case REF_MSPHERE: {
@@ -470,7 +477,7 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
     }
     case GEOM_SPHERES:
         for (uint32_t k = 0; k < o.count; k++) {
-            SphereGeom g = sc.spheres[o.first + k];
+            SphereGeom g = get_sphere(sc, o.first + k);
             double t;
             if (sphere_test(lr.o - mk(g.cx, g.cy, g.cz), lr.d, a, g.r2, tmin, closest, t)) {
                 any = true;
@@ -549,7 +556,7 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
         // has its row repeated in the medium record (one table less to chase through).
         SphereGeom g;
         if (med.sphere != kNone) g = SphereGeom{med.cx, med.cy, med.cz, med.r2};
-        else g = sc.spheres[o.first & kRefIndexMask];
+        else g = get_sphere(sc, o.first & kRefIndexMask);
         const Vec oc = lr.o - mk(g.cx, g.cy, g.cz);
         const double a = dot(lr.d, lr.d);
         const double b = dot(oc, lr.d);
@@ -653,7 +660,7 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
         }
         uint32_t call = kNone;   // child to call next, with [call_tmin, call_tmax]
         double call_tmin = 0.0, call_tmax = 0.0;
-        bool done = false, answer = false;
+        bool answer = false;  // what this call answers, unless it first calls a child (`call`)
         switch (n.kind) {
         case TN_PRIM: {
             double t;
@@ -663,7 +670,6 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
                 best.ref = n.a;
                 best.obj = kTreeObjBit | f.node;
             }
-            done = true;
             break;
         }
         case TN_TRANSLATE:
@@ -672,7 +678,6 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
                 f.step = 1;
                 call = n.a; call_tmin = f.tmin; call_tmax = f.tmax;
             } else {
-                done = true;
                 answer = ret;
             }
             break;
@@ -686,7 +691,6 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
                 call_tmin = f.tmin; call_tmax = f.closest;
                 f.step++;
             } else {
-                done = true;
                 answer = f.any != 0;
             }
             break;
@@ -698,7 +702,6 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
             } else if (f.step == 1) {
                 if (!ret) {
                     best = f.saved;
-                    done = true;
                 } else {
                     f.closest = best.t;  // rec1.T
                     f.step = 2;
@@ -708,7 +711,6 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
                 double t1 = f.closest, t2 = best.t;
                 const bool second = ret;
                 best = f.saved;
-                done = true;
                 if (second) {
                     if (t1 < f.tmin) t1 = f.tmin;
                     if (t2 > f.tmax) t2 = f.tmax;
@@ -733,12 +735,11 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
         default: {  // TN_BVH
             if (f.cursor == kNone) f.cursor = n.a;  // first entry: the root of this BvhNode's threaded nodes
             for (;;) {
-                const BvhNodeRec node = sc.nodes[f.cursor];
+                const BvhNodeRec node = sc.tree_bvh[f.cursor];
                 if (f.step == 0) {
                     const Vec inv = mk(1.0 / lr.d.x, 1.0 / lr.d.y, 1.0 / lr.d.z);
                     if (!box_test(node.xlo, node.xhi, node.ylo, node.yhi, node.zlo, node.zhi, lr, inv, f.tmin, f.closest)) {
                         if (node.escape == kNone) {
-                            done = true;
                             answer = f.any != 0;
                             break;
                         }
@@ -773,7 +774,6 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
                 const bool has_inner = (node.a >> kRefShift) == REF_INNER || (node.b >> kRefShift) == REF_INNER;
                 const uint32_t next = has_inner ? f.cursor + 1u : node.escape;
                 if (next == kNone) {
-                    done = true;
                     answer = f.any != 0;
                     break;
                 }
@@ -796,7 +796,8 @@ DEV bool tree_hit(const DeviceScene &sc, uint32_t root, const Ray &r, double tmi
     }
 }
 
-DEV bool is_medium_leaf(uint32_t ref) { return (ref >> kRefShift) == REF_MOBJECT; }  // tagged by the flattener
+// a leaf whose test may draw random numbers (tagged by the flattener): a ConstantMedium object, or a tree (may hold media)
+DEV bool is_medium_leaf(uint32_t ref) { return (ref >> kRefShift) == REF_MOBJECT || (ref >> kRefShift) == REF_TREE; }
 
 template <class T>
 DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
@@ -1096,29 +1097,48 @@ DEV void walk_object_pass(const DeviceScene &sc, const NodeView &nv, const Ray &
         const double tmax = bcast(w.closest, src);
         const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)o.coop_first, src);
         const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)o.count, src);
+        const uint32_t boxes = (uint32_t)__builtin_amdgcn_readlane((int)o.coop_boxes, src);
         const double a = dot(q.d, q.d);
         double bt = tmax;
         uint32_t bk = kNone;
-        for (uint32_t base = 0; base < count; base += 256u) {
-            double b[4], c[4], disc[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {  // four independent rows in flight per lane
-                uint32_t k = base + 64u * u + lane;
-                k = k < count ? k : count - 1u;  // stays inside the group's rows
-                const SphereGeom g = sc.spheres[first + k];
-                Vec oc = q.o - mk(g.cx, g.cy, g.cz);
-                b[u] = dot(oc, q.d);
-                c[u] = dot(oc, oc) - g.r2;
-                disc[u] = b[u] * b[u] - a * c[u];
+        // Cull by groups of sixteen rows: lane g slab-tests the padded box of group g (R/AABB.h's test, conservative here),
+        // then the wave tests only the spheres of the groups the ray passes, four groups (64 spheres) at a time.  A zero
+        // direction component would put NaNs into the slab test: such a ray (none in practice) culls nothing.
+        const bool axis_parallel = q.d.x == 0.0 || q.d.y == 0.0 || q.d.z == 0.0;
+        const Vec inv = mk(1.0 / q.d.x, 1.0 / q.d.y, 1.0 / q.d.z);
+        const uint32_t n_groups = (count + kCoopGroup - 1u) / kCoopGroup;
+        for (uint32_t g0 = 0; g0 < n_groups; g0 += 64u) {
+            const uint32_t g = g0 + lane;
+            bool pass = g < n_groups;
+            if (pass && !axis_parallel) {
+                const GroupBox gb = get_group_box(sc, boxes + g);
+                pass = box_test(gb.lo[0], gb.hi[0], gb.lo[1], gb.hi[1], gb.lo[2], gb.hi[2], q, inv, tmin, tmax);
             }
+            unsigned long long hits = __ballot(pass);
+            while (hits) {
+                // the (lane / 16)-th of the next four passing groups is mine
+                unsigned long long m = hits;
+                int mine_g = -1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t k = base + 64u * u + lane;
-                if (k < count && disc[u] > 0.0 && !(tmin >= 0.0 && b[u] > 0.0 && c[u] > 0.0)) {  // see sphere_test
-                    double t;
-                    if (sphere_roots(b[u], disc[u], a, tmin, bt, t)) {
-                        bt = t;
-                        bk = k;
+                for (int j = 0; j < 4; j++) {
+                    const int bit = m ? __ffsll((long long)m) - 1 : -1;
+                    if ((int)(lane >> 4) == j) mine_g = bit;
+                    m = m ? (m & (m - 1)) : 0ull;
+                }
+                hits = m;
+                const uint32_t k = mine_g >= 0 ? (g0 + (uint32_t)mine_g) * kCoopGroup + (lane & 15u) : count;
+                if (k < count) {
+                    const SphereGeom sg = get_sphere(sc, first + k);
+                    const Vec oc = q.o - mk(sg.cx, sg.cy, sg.cz);
+                    const double b = dot(oc, q.d);
+                    const double c = dot(oc, oc) - sg.r2;
+                    const double disc = b * b - a * c;
+                    if (disc > 0.0 && !(tmin >= 0.0 && b > 0.0 && c > 0.0)) {  // see sphere_test
+                        double t;
+                        if (sphere_roots(b, disc, a, tmin, bt, t)) {
+                            bt = t;
+                            bk = k;
+                        }
                     }
                 }
             }
@@ -1636,7 +1656,7 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
         Vec c;
         SphereAux aux;
         if (T::WORLD == 2 || tag == REF_SPHERE) {
-            SphereGeom g = sc.spheres[idx];
+            SphereGeom g = T::COMPOSITE ? get_sphere(sc, idx) : sc.spheres[idx];
             c = mk(g.cx, g.cy, g.cz);
             aux = sc.sphere_aux[idx];
         } else {
@@ -1945,7 +1965,7 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a)
 
 
 template <int STRICT, class T>
-__global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene sc, RenderArgs a)
+__global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceScene sc, RenderArgs a)
 {
     // ---- chip-resident working set ----
     NodeView nv{};
@@ -1980,6 +2000,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         stage(sc.lds_objects, sc.objects, sc.n_objects * (uint32_t)sizeof(ObjectRec));
         stage(sc.lds_xforms, sc.xforms, sc.n_xforms * (uint32_t)sizeof(Xform));
         stage(sc.lds_media, sc.media, sc.n_media * (uint32_t)sizeof(MediumRec));
+        stage(sc.lds_spheres_tab, sc.spheres, sc.n_spheres * (uint32_t)sizeof(SphereGeom));
+        stage(sc.lds_group_boxes, sc.group_boxes, sc.n_group_boxes * (uint32_t)sizeof(GroupBox));
         stage(sc.lds_materials, sc.materials, sc.n_materials * (uint32_t)sizeof(MaterialRec));
         if constexpr (T::RICH) stage(sc.lds_perlin, sc.perlin, sc.n_perlin * (uint32_t)sizeof(PerlinRec));
         __syncthreads();  // uniform: every thread of the block gets here
@@ -1992,7 +2014,7 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
         sv.n_padded = (sc.n_spheres + 63u) & ~63u;
         sv.in_lds = a.lds_spheres != 0;
         if (sv.in_lds) {
-            sv.planes_off = 4u * kQueueCap * 64u * (uint32_t)sizeof(uint16_t);
+            sv.planes_off = ((uint32_t)T::BLOCK / 64u) * kQueueCap * 64u * (uint32_t)sizeof(uint16_t);
             double *planes = reinterpret_cast<double *>(lds_raw + sv.planes_off);
             const uint32_t np = sv.n_padded;
             for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
@@ -2008,7 +2030,12 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
     // start on neighbouring pixels; a slot outside the frame is simply skipped.
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = ((uint32_t)a.width + 7u) >> 3;
-    const uint32_t total_slots = tiles_x * (((uint32_t)a.rows_owned + 7u) >> 3) * 64u;
+    // the work queue: tile-major slots of this rank's rows, or the entries of a pixel list (see RenderArgs::pixel_list)
+    const uint32_t total_slots = a.pixel_list ? *(const RT_CONST uint32_t *)(uintptr_t)a.pixel_list_count
+                                              : tiles_x * (((uint32_t)a.rows_owned + 7u) >> 3) * 64u;
+    if (a.wave_priority == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.wave_priority == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.wave_priority == 3) __builtin_amdgcn_s_setprio(3);
     const CameraRec *__restrict__ cam = sc.camera;
 
     bool active = false, exhausted = false;
@@ -2060,10 +2087,9 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
 
         if (!exhausted && !boost) {
             unsigned long long need = __ballot(!active);
-            if constexpr (T::WORLD == 2) {
-                // pixels_per_wave < 64: only the first lanes take pixels; the others lend themselves to the grouped scan
-                if (a.pixels_per_wave < 64) need &= (1ull << a.pixels_per_wave) - 1ull;
-            }
+            // pixels_per_wave < 64: only the first lanes take pixels.  Sphere-list kernel: the others lend themselves to the
+            // grouped scan; BVH kernels: the few rays have the wave's phases to themselves (shorter chain per pixel).
+            if (a.pixels_per_wave < 64) need &= (1ull << a.pixels_per_wave) - 1ull;
             if (need) {
                 PH_BEGIN();
                 [[maybe_unused]] const bool ph_was_idle = !active;
@@ -2079,10 +2105,20 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                 if (((need >> lane) & 1ull) && slot < total_slots) {
                     // heaviest tiles first when the launcher has ranked them (see rt_render_launch); else row-major
                     const uint32_t w = slot & 63u;
-                    const uint32_t tile = (RT_ORDER_ON && a.tile_order) ? a.tile_order[slot >> 6] : slot >> 6;
-                    const int pi = (int)((tile % tiles_x) * 8u + (w & 7u));
-                    const int lr = (int)((tile / tiles_x) * 8u + (w >> 3));
-                    if (pi < a.width && lr < a.rows_owned) {
+                    uint32_t tile = (RT_ORDER_ON && a.tile_order && !a.pixel_list) ? a.tile_order[slot >> 6] : slot >> 6;
+                    int pi = (int)((tile % tiles_x) * 8u + (w & 7u));
+                    int lr = (int)((tile / tiles_x) * 8u + (w >> 3));
+                    bool take = pi < a.width && lr < a.rows_owned;
+                    if (a.pixel_list) {  // listed pixels: compact index -> row, column
+                        const uint32_t loc = a.pixel_list[slot];
+                        lr = (int)(loc / (uint32_t)a.width);
+                        pi = (int)(loc % (uint32_t)a.width);
+                        tile = ((uint32_t)lr >> 3) * tiles_x + ((uint32_t)pi >> 3);
+                        take = true;
+                    } else if (a.pix_class && take) {
+                        take = a.pix_class[(size_t)lr * (size_t)a.width + (size_t)pi] == 0;  // the other launch's pixel
+                    }
+                    if (take) {
                         i = pi;
                         j = owned_row(lr, a.stripe_rows, a.rank, a.world_size);
                         local = (size_t)lr * (size_t)a.width + (size_t)pi;
@@ -2283,7 +2319,8 @@ __global__ __launch_bounds__(256, T::MIN_WAVES) void render_kernel(DeviceScene s
                     depth = 0;
                 } else if (RT_PROBE_ON && a.probe) {
                     // cost probe: the samples were a rehearsal (the saved RNG state is untouched); book the rays
-                    atomicAdd(a.tile_cost + my_tile, pix_rays);
+                    if (a.tile_cost) atomicAdd(a.tile_cost + my_tile, pix_rays);
+                    if (a.pix_cost) a.pix_cost[local] = pix_rays;
                     active = false;
                 } else {
                     // R/kernel.cu:146-153: save the RNG state, average, gamma 2
@@ -2398,6 +2435,25 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, 
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) order[atomicAdd(&hist[klass(cost[k])], 1u)] = k;
 }
 
+__global__ __launch_bounds__(256) void classify_pixels_kernel(const uint32_t *cost, uint32_t n, uint32_t threshold, uint8_t *klass,
+                                                               uint32_t *list, uint32_t *count)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const bool heavy = cost[k] >= threshold;
+    klass[k] = heavy ? 1 : 0;
+    if (heavy) list[atomicAdd(count, 1u)] = k;  // order within the list is irrelevant: every listed pixel starts at once
+}
+
+hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, uint32_t threshold, uint8_t *pix_class, uint32_t *list,
+                                  uint32_t *count, hipStream_t stream)
+{
+    if (n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(classify_pixels_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, pix_cost, n_pixels, threshold,
+                       pix_class, list, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
@@ -2450,7 +2506,10 @@ using TBvhMedia = Traits<0, true, false, 3, true>;                      // + Con
 #ifndef RT_WAVES_DEEP
 #define RT_WAVES_DEEP 3
 #endif
-using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP, true, true>;
+#ifndef RT_BLOCK_DEEP
+#define RT_BLOCK_DEEP 768
+#endif
+using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP, true, true, false, RT_BLOCK_DEEP>;
 // List scans over primitives / instances without media or table-walking textures.  Also the BVH worlds of small
 // scenes: for up to 16 leaves within a cost budget (FlatScene::scan_cost) a scan of all of them in the tree's leaf order -- every lane on the same leaf, rows
 // through uniform loads, no node visits, no phases -- beats walking the tree (Cornell box: 8 leaves, 7 nodes).  Without
@@ -2474,7 +2533,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
     a.lds_nodes = 0;
     if (T::WORLD == 0) {
         size_t need = (size_t)sc.n_world_nodes * kLdsNodeBytes;
-        if (need <= 60 * 1024) {  // keep >= 2 workgroups per CU resident
+        if (need <= 60 * 1024) {  // keep >= 2 workgroups (of 256 threads) per CU resident
             lds = need;
             a.lds_nodes = 1;
         }
@@ -2482,7 +2541,8 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             // Small tables ride along behind the node rows, each on its own merits: the records a leaf test or the shading
             // chases through (object -> transforms -> medium; material rows; Perlin tables: a few KB even in the Book-2
             // final scene) and, where they fit as well, the quad / box rows (Cornell box: 2 KB).
-            const size_t budget = 52 * 1024;  // three workgroups per CU
+            // three 256-thread workgroups per CU share its 160 KB, or one of 768 threads has (nearly) all of it
+            const size_t budget = T::BLOCK >= 768 ? 158 * 1024 : 52 * 1024;
             size_t off = (lds + 15) & ~(size_t)15;
             auto place = [&](uint32_t &slot, size_t bytes, size_t cap) {
                 if (bytes == 0 || bytes > cap || off + bytes + 64 > budget) return;
@@ -2492,17 +2552,22 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             place(sc.lds_objects, (size_t)sc.n_objects * sizeof(ObjectRec), 4096);
             place(sc.lds_xforms, (size_t)sc.n_xforms * sizeof(Xform), 4096);
             place(sc.lds_media, (size_t)sc.n_media * sizeof(MediumRec), 2048);
+            place(sc.lds_group_boxes, (size_t)sc.n_group_boxes * sizeof(GroupBox), 4096);
             place(sc.lds_materials, (size_t)sc.n_materials * sizeof(MaterialRec), 4096);
             if (T::RICH) place(sc.lds_perlin, (size_t)sc.n_perlin * sizeof(PerlinRec), 2 * sizeof(PerlinRec));
             const size_t b_quads = (size_t)sc.n_quads * sizeof(AAQuad), b_boxes = (size_t)sc.n_boxes * sizeof(BoxRec);
-            if (b_quads + b_boxes <= 16 * 1024 && off + b_quads + b_boxes + 96 <= budget) {
+            if (T::BLOCK >= 768) {  // the big tables, most useful first
+                place(sc.lds_boxes, b_boxes, 80 * 1024);
+                place(sc.lds_spheres_tab, (size_t)sc.n_spheres * sizeof(SphereGeom), 40 * 1024);
+                place(sc.lds_quad_aa, b_quads, 16 * 1024);
+            } else if (b_quads + b_boxes <= 16 * 1024 && off + b_quads + b_boxes + 96 <= budget) {
                 place(sc.lds_quad_aa, b_quads, 16 * 1024);
                 place(sc.lds_boxes, b_boxes, 16 * 1024);
             }
             lds = off;
         }
     } else if (T::WORLD == 2) {
-        lds = 4 * kQueueCap * 64 * sizeof(uint16_t);
+        lds = (T::BLOCK / 64) * kQueueCap * 64 * sizeof(uint16_t);
         size_t planes = (size_t)((sc.n_spheres + 63u) & ~63u) * 4 * sizeof(double);
         a.lds_spheres = 0;
         if (planes <= 48 * 1024) {
@@ -2522,7 +2587,11 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
     if (a.n_pixels == 0 || a.spp <= 0) return hipSuccess;
     // persistent grid: as many workgroups as the chip holds at once (never more than there are tiles)
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds);
+    if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: ask for it (up to the CU's 160 KB)
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
+    }
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, T::BLOCK, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     // Sphere-list worlds: two resident workgroups per CU beat three although three fit -- a third wave per SIMD
@@ -2530,10 +2599,12 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
     int cap = a.max_blocks_per_cu > 0 ? a.max_blocks_per_cu : (T::WORLD == 2 ? 2 : 0);
     if (cap > 0 && per_cu > cap) per_cu = cap;
     uint32_t resident = (uint32_t)per_cu * (uint32_t)(a.num_cus > 0 ? a.num_cus : 256);
-    uint32_t blocks = (tiles + 3u) / 4u;
+    constexpr uint32_t kWavesPerBlock = (uint32_t)T::BLOCK / 64u;
+    uint32_t blocks = (tiles + kWavesPerBlock - 1u) / kWavesPerBlock;
+    if (a.pixel_list) blocks = resident;  // a pixel list's length lives on the device: the launcher caps the grid (grid_blocks)
     if (blocks > resident) blocks = resident;
     if (a.grid_blocks > 0 && blocks > (uint32_t)a.grid_blocks) blocks = (uint32_t)a.grid_blocks;  // tuning experiments
-    dim3 grid(blocks), block(256);
+    dim3 grid(blocks), block(T::BLOCK);
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, sc, a);
     return hipGetLastError();
 }

@@ -29,7 +29,15 @@ struct RenderArgs {
     uint32_t *cursor;            // pixel-queue cursor, zeroed before every launch
     uint32_t *tile_cost;        // probe launches: rays traced per 8x8 tile (one counter per tile of this rank's rows)
     const uint32_t *tile_order; // render launches: queue position -> tile (nullptr = tiles in row-major order)
-    int32_t probe;              // 1 = cost probe: trace `spp` samples per pixel, write nothing but tile_cost
+    int32_t probe;              // 1 = cost probe: trace `spp` samples per pixel, write nothing but tile_cost / pix_cost
+    // Sphere-list worlds, two classes of pixels (device_scene.cpp rt_render_launch): the probe books every pixel's rays in
+    // pix_cost; classify_pixels marks the heavy ones in pix_class and lists them; the frame is then two launches -- the
+    // listed pixels (pixel_list, a few lanes-per-ray waves, started first) and all the others (pix_class != 0 is skipped).
+    uint32_t *pix_cost;               // probe launches: rays traced by each owned pixel
+    const uint32_t *pixel_list;       // render launch over a list of owned pixels (compact indices) instead of the tile queue
+    const uint32_t *pixel_list_count; // device word holding the length of pixel_list
+    const uint8_t *pix_class;         // tile-queue launches: pixels whose class is non-zero belong to another launch
+    int32_t wave_priority;            // s_setprio for this launch's waves (0..3)
     uint32_t n_pixels;
     int32_t width, height, rows_owned;
     int32_t spp, max_depth;
@@ -65,6 +73,11 @@ hipError_t launch_render_strict(const DeviceScene &sc, const RenderArgs &a, hipS
 hipError_t launch_render_fast(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream);
 hipError_t kernel_info_strict(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info);
 hipError_t kernel_info_fast(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info);
+
+// class 1 + an entry in `list` (its length in *count, which the caller has zeroed) for every pixel whose probed cost is at
+// least `threshold` rays, class 0 for the others
+hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, uint32_t threshold, uint8_t *pix_class, uint32_t *list,
+                                  uint32_t *count, hipStream_t stream);
 
 // tile_order[k] = the tile with the k-th highest cost (counting sort over 256 cost classes; one workgroup)
 hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, hipStream_t stream);

@@ -429,7 +429,9 @@ struct Flattener {
             f.tree_items.insert(f.tree_items.end(), kids.begin(), kids.end());
         } else {  // HKind::Bvh
             rec.kind = TN_BVH;
-            rec.a = thread_tree_general(h, 0, kNone, chain, depth + 1);
+            std::vector<uint32_t> node_of(s.hittables.size() + 1, kNone);
+            lower_bvh_leaves(h, chain, depth + 1, node_of);
+            rec.a = thread_tree_general(h, 0, kNone, node_of);
         }
         f.tree_nodes[me] = rec;
         return me;
@@ -439,11 +441,24 @@ struct Flattener {
     // spliced in as an inner child -- a node may then hold one leaf and one inner child, and a span-1 node over a BvhNode
     // object walks that object's tree twice.  a / b = REF_TREE | tree node for a leaf, the REF_INNER marker for an inner
     // child; the inner children follow the node in order, the first one at n + 1.
-    uint32_t thread_tree_general(const HostHittable &bvh, int ti, uint32_t escape, const std::vector<Xform> &chain, uint32_t depth)
+    // Leaves are lowered first (lower_bvh_leaves): a leaf may hold BvhNodes of its own, whose nodes must not land between a
+    // node and its first inner child.
+    void lower_bvh_leaves(const HostHittable &bvh, const std::vector<Xform> &chain, uint32_t depth, std::vector<uint32_t> &node_of)
+    {
+        for (const auto &tn : bvh.tree) {
+            if (tn.left >= 0) continue;
+            for (uint32_t hnd : {tn.leaf_a, tn.leaf_b}) {
+                const HostHittable &obj = s.hittables[hnd - 1];
+                if (obj.kind == HKind::Bvh) lower_bvh_leaves(obj, chain, depth, node_of);
+                else if (node_of[hnd] == kNone) node_of[hnd] = lower_tree(hnd, chain, depth);
+            }
+        }
+    }
+    uint32_t thread_tree_general(const HostHittable &bvh, int ti, uint32_t escape, const std::vector<uint32_t> &node_of)
     {
         const auto &tn = bvh.tree[ti];
-        const uint32_t me = (uint32_t)f.nodes.size();
-        f.nodes.push_back({});
+        const uint32_t me = (uint32_t)f.tree_bvh.size();
+        f.tree_bvh.push_back({});
         BvhNodeRec rec{};
         rec.xlo = tn.box.lo[0]; rec.xhi = tn.box.hi[0];
         rec.ylo = tn.box.lo[1]; rec.yhi = tn.box.hi[1];
@@ -463,10 +478,10 @@ struct Flattener {
         }
         uint32_t refs[2];
         for (int c = 0; c < 2; c++)
-            refs[c] = kid[c].inner ? make_ref(REF_INNER, 0) : make_ref(REF_TREE, lower_tree(kid[c].leaf, chain, depth));
+            refs[c] = kid[c].inner ? make_ref(REF_INNER, 0) : make_ref(REF_TREE, node_of[kid[c].leaf]);
         rec.a = refs[0];
         rec.b = refs[1];
-        f.nodes[me] = rec;
+        f.tree_bvh[me] = rec;
         // inner children in order; the first one's walk escapes to the second one, the last one's to this node's escape
         const int n_inner = (kid[0].inner ? 1 : 0) + (kid[1].inner ? 1 : 0);
         int seen = 0;
@@ -475,14 +490,14 @@ struct Flattener {
             if (!kid[c].inner) continue;
             seen++;
             if (seen == 1 && n_inner == 2) {
-                first_begin = f.nodes.size();
-                thread_tree_general(*kid[c].owner, kid[c].index, kNone - 1 /* placeholder */, chain, depth);
-                first_end = f.nodes.size();
+                first_begin = f.tree_bvh.size();
+                thread_tree_general(*kid[c].owner, kid[c].index, kNone - 1 /* placeholder */, node_of);
+                first_end = f.tree_bvh.size();
             } else {
                 if (n_inner == 2)
                     for (size_t k = first_begin; k < first_end; k++)
-                        if (f.nodes[k].escape == kNone - 1) f.nodes[k].escape = (uint32_t)f.nodes.size();
-                thread_tree_general(*kid[c].owner, kid[c].index, escape, chain, depth);
+                        if (f.tree_bvh[k].escape == kNone - 1) f.tree_bvh[k].escape = (uint32_t)f.tree_bvh.size();
+                thread_tree_general(*kid[c].owner, kid[c].index, escape, node_of);
             }
         }
         return me;
@@ -501,6 +516,7 @@ struct Flattener {
         ObjectRec obj{};
         obj.medium = kNone;
         obj.coop_first = kNone;
+        obj.coop_boxes = kNone;
         if (h->kind == HKind::Medium) {
             f.media.push_back({h->neg_inv_density, h->material - 1, kNone, 0.0, 0.0, 0.0, 0.0});
             obj.medium = (uint32_t)f.media.size() - 1;
@@ -552,7 +568,29 @@ struct Flattener {
                 for (uint32_t hnd : objs)
                     if (ref_of[hnd] == kNone) ref_of[hnd] = add_primitive(s.hittables[hnd - 1]);
                 // all static spheres, each listed once: the rows just added are this group's, contiguously
-                if (all_s && f.spheres.size() - spheres_before == prims.size()) obj.coop_first = (uint32_t)spheres_before;
+                if (all_s && f.spheres.size() - spheres_before == prims.size()) {
+                    obj.coop_first = (uint32_t)spheres_before;
+                    obj.coop_boxes = (uint32_t)f.group_boxes.size();
+                    for (size_t g0 = 0; g0 < prims.size(); g0 += kCoopGroup) {
+                        GroupBox gb;
+                        for (int k = 0; k < 3; k++) {
+                            gb.lo[k] = DBL_MAX;
+                            gb.hi[k] = -DBL_MAX;
+                        }
+                        for (size_t k = g0; k < g0 + kCoopGroup && k < prims.size(); k++) {
+                            const SphereGeom &sg = f.spheres[spheres_before + k];
+                            const double r = std::sqrt(sg.r2), c[3] = {sg.cx, sg.cy, sg.cz};
+                            for (int a2 = 0; a2 < 3; a2++) {
+                                // outwards by a part in 2^20 of the magnitudes involved: far beyond any rounding of the slab
+                                // test or of the sphere's own arithmetic, far below anything that would cost culling power
+                                const double pad = 9.5367431640625e-07 * (std::fabs(c[a2]) + r) + 1e-300;
+                                gb.lo[a2] = std::fmin(gb.lo[a2], c[a2] - r - pad);
+                                gb.hi[a2] = std::fmax(gb.hi[a2], c[a2] + r + pad);
+                            }
+                        }
+                        f.group_boxes.push_back(gb);
+                    }
+                }
                 obj.geom_kind = GEOM_BVH;
                 obj.first = kNone;  // patched by emit_pending()
                 pending.push_back({(uint32_t)f.objects.size(), std::move(sub), std::move(ref_of)});

@@ -71,8 +71,10 @@ struct FlatScene {
     std::vector<uint32_t> items;
     std::vector<Xform> xforms;
     std::vector<MediumRec> media;
+    std::vector<GroupBox> group_boxes;
     std::vector<TreeNodeRec> tree_nodes;
     std::vector<uint32_t> tree_items;
+    std::vector<BvhNodeRec> tree_bvh;
     std::vector<BvhNodeRec> nodes;
     std::vector<uint32_t> world_items;   // leaf refs in final order (both world kinds)
     std::vector<Box> leaf_boxes;         // introspection

@@ -549,3 +549,25 @@ def test_thin_wave_scan_of_a_sphere_bvh_world_equals_the_walk(oracle, scene_id, 
     assert np.array_equal(walk.view(np.uint64), dflt.view(np.uint64))
     want = oracle.render(scene_id, 0, w, h, spp)
     assert np.array_equal(scan.view(np.uint64), want.view(np.uint64))
+
+
+def test_heavy_and_light_pixels_in_two_launches_give_the_same_frame(oracle):
+    """Sphere-list worlds (config C2): a rehearsal of the first samples finds the pixels with long ray chains (glass);
+    they are rendered by a launch of their own, a few pixels per wave with the lanes sharing each ray's scan, beside the
+    launch of all the others.  Every pixel is rendered exactly once from its own RNG stream, so the frame, the ray count
+    and the saved RNG state are those of the single launch (RT_FLAG_NO_PIXEL_CLASSES = 64); rows against the oracle too."""
+    w, h, spp = 512, 256, 64          # 131072 pixels: the smallest frame that is split
+    s = rt.builtin_scene(11, 1, w, h)
+    film_a, film_b = rt.Film(w, h), rt.Film(w, h)
+    st_a = film_a.render(s, spp, variant=0)
+    st_b = film_b.render(s, spp, variant=0, flags=64)
+    a, b = film_a.download(), film_b.download()
+    assert st_a.kernel_kind == 16
+    assert st_a.rays == st_b.rays and st_a.samples == st_b.samples == w * h * spp
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    want = oracle.render(11, 1, w, h, spp, rows=(96, 100))
+    assert np.array_equal(a[96:100].view(np.uint64), want[96:100].view(np.uint64))
+    # progressive continuation from the saved streams: both films carry on identically
+    film_a.render(s, 8, variant=0, flags=1)
+    film_b.render(s, 8, variant=0, flags=1 | 64)
+    assert np.array_equal(film_a.download().view(np.uint64), film_b.download().view(np.uint64))

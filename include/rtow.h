@@ -133,6 +133,9 @@ RTOW_API int rt_scene_get_info(rt_scene *s, rt_scene_info *out);
 RTOW_API int rt_scene_dump_leaves(rt_scene *s, int max_leaves, int *kind_out, double *box_out);
 /* Threaded-BVH nodes in preorder: box[6], a, b, escape per node (a,b = leaf refs or 0xE0000000 for inner). */
 RTOW_API int rt_scene_dump_nodes(rt_scene *s, int max_nodes, double *box_out, uint32_t *abe_out);
+/* The library's own tree for primitive-only BVH worlds (0 nodes if the world has none): box[6], a, b, and per direction
+ * octant the {hit, escape} links (16 x uint16 per node, 0xFFFF = end). */
+RTOW_API int rt_scene_dump_fast_nodes(rt_scene *s, int max_nodes, double *box_out, uint32_t *ab_out, uint16_t *link_out);
 RTOW_API int rt_scene_dump_camera(rt_scene *s, double out27[27]);
 
 /* ---- render (RenderInit + Render, R/kernel.cu:110-154,675-691) ---- */
@@ -167,6 +170,9 @@ typedef struct rt_render_params {
 #define RT_FLAG_NO_PIXEL_CLASSES 64u /* sphere-list worlds: render every pixel in one launch (default: a rehearsal of the first samples finds the
                                       few pixels with long ray chains, which a launch of their own renders with several lanes per ray beside
                                       the launch of all the others; the image is the same either way) */
+#define RT_FLAG_REFERENCE_TREE 128u  /* BVH worlds of primitives only are walked through the library's own tree (surface-area heuristic, near
+                                      child first) -- no leaf draws random numbers there, so the closest hit is the one the reference's tree
+                                      gives; this flag walks the reference's own tree in its own order instead (tests, timing) */
 #define RT_FLAG_ROW_MAJOR_TILES 16u /* BVH worlds: keep the pixel queue in row-major tile order (default: a short rehearsal ranks
                                       the 8x8 tiles by rays traced and the heaviest start first; the image is the same either way) */
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "rt_scene_get_info": (I, [P, C.POINTER(SceneInfo)]),
     "rt_scene_dump_leaves": (I, [P, I, C.POINTER(C.c_int), D3]),
     "rt_scene_dump_nodes": (I, [P, I, D3, C.POINTER(C.c_uint32)]),
+    "rt_scene_dump_fast_nodes": (I, [P, I, D3, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]),
     "rt_scene_dump_camera": (I, [P, D3]),
     "rt_stripe_rows": (I, [I, I, I, I, C.POINTER(C.c_int), I]),
     "rt_film_create": (P, [I, I, I, I, I, I]),

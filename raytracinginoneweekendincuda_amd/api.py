@@ -25,6 +25,7 @@ FLAG_OVERDUE_PRIORITY = 4   # diagnostics
 FLAG_ACCUMULATE = 8         # with KEEP_RNG_STATE: add this launch's samples to the film's running sums
 FLAG_ROW_MAJOR_TILES = 16   # BVH worlds: keep the pixel queue in row-major tile order (no cost ranking)
 FLAG_ALWAYS_WALK = 32       # small BVH worlds: walk the tree instead of scanning all leaves
+FLAG_REFERENCE_TREE = 128   # primitive BVH worlds: walk the reference's own tree (default: the library's SAH tree)
 FLAG_NO_PIXEL_CLASSES = 64  # sphere-list worlds: one launch for all pixels (no separate launch for the long-chain pixels)
 
 
@@ -211,6 +212,18 @@ class Scene:
         abe = np.zeros((max(n, 1), 3), dtype=np.uint32)
         lib().rt_scene_dump_nodes(self._p, n, boxes.ctypes.data_as(_lib.D3), abe.ctypes.data_as(C.POINTER(C.c_uint32)))
         return boxes[:n], abe[:n]
+
+    def dump_fast_nodes(self):
+        """The library's own tree for a primitive-only BVH world: boxes (n, 6), leaf refs (n, 2), octant links (n, 8, 2)."""
+        n = lib().rt_scene_dump_fast_nodes(self._p, 0, None, None, None)
+        if n < 0:
+            raise RtowError(_err())
+        boxes = np.zeros((max(n, 1), 6), dtype=np.float64)
+        ab = np.zeros((max(n, 1), 2), dtype=np.uint32)
+        links = np.zeros((max(n, 1), 8, 2), dtype=np.uint16)
+        lib().rt_scene_dump_fast_nodes(self._p, n, boxes.ctypes.data_as(_lib.D3), ab.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       links.ctypes.data_as(C.POINTER(C.c_uint16)))
+        return boxes[:n], ab[:n], links[:n]
 
     def dump_camera(self):
         out = np.zeros(27, dtype=np.float64)

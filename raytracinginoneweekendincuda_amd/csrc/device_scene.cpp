@@ -175,6 +175,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.tree_items, d.tree_items);
     up(f.tree_bvh, d.tree_bvh);
     up(f.nodes, d.nodes);
+    up(f.fast_nodes, d.fast_nodes);
     up(f.world_items, d.world_items);
     up(f.materials, d.materials);
     up(f.textures, d.textures);
@@ -200,6 +201,8 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_xforms = (uint32_t)f.xforms.size();
     if (!(f.flags & SCENE_WORLD_MSPHERES)) d.ms_planes = nullptr;
     d.ms_padded = f.ms_padded;
+    d.n_fast_nodes = (uint32_t)f.fast_nodes.size();
+    if (f.fast_nodes.empty()) d.fast_nodes = nullptr;
     d.n_media = (uint32_t)f.media.size();
     d.n_materials = (uint32_t)f.materials.size();
     d.n_perlin = (uint32_t)f.perlin.size();
@@ -365,11 +368,13 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     {
         const uint32_t world_nodes = s.flat.n_world_nodes;
         ra.node_burst = world_nodes > 64 ? 24 : 8;
-        ra.park_ratio = world_nodes > 64 ? 8 : 1;
+        ra.park_ratio = world_nodes > 64 ? 4 : 1;
         if (const char *e = std::getenv("RTOW_BURST")) ra.node_burst = std::atoi(e);  // experiments only
         if (const char *e = std::getenv("RTOW_PARK")) ra.park_ratio = std::atoi(e);
-        ra.leaf_batch = 8;
+        ra.leaf_batch = 12;
         ra.object_batch = 4;
+        ra.rounds = 4;
+        if (const char *e = std::getenv("RTOW_ROUNDS")) ra.rounds = std::atoi(e);
         if (const char *e = std::getenv("RTOW_LEAF_BATCH")) ra.leaf_batch = std::atoi(e);
         if (const char *e = std::getenv("RTOW_OBJECT_BATCH")) ra.object_batch = std::atoi(e);
     }
@@ -393,6 +398,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.world_size = f.world_size;
     ra.force_general = (p->flags & RT_FLAG_FORCE_GENERAL) ? 1 : 0;
     ra.always_walk = (p->flags & RT_FLAG_ALWAYS_WALK) ? 1 : 0;
+    ra.reference_tree = (p->flags & RT_FLAG_REFERENCE_TREE) ? 1 : 0;
     ra.small_world = 64;  // scan budget in half sphere tests, see FlatScene::scan_cost
     if (const char *e = std::getenv("RTOW_SMALL_WORLD")) ra.small_world = std::atoi(e);  // experiments only
     const DeviceScene &ds = s.device[f.device]->scene;
@@ -400,7 +406,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     // BVH sphere worlds: thin waves may scan all leaves together instead of walking (scan_grouped_ms), but the planes
     // come from L2 and a chip full of thin waves scanning is bound by L2 bandwidth: measured slower than walking at every
     // threshold (C3: 1748 Msamples/s never, 1681 at 17, 1048 at 33).  Off unless asked for.
-    if (f.last_kernel.kind < 8 && p->coop_threshold <= 0) ra.coop_threshold = 0;
+    if ((f.last_kernel.kind & 63) < 8 && p->coop_threshold <= 0) ra.coop_threshold = 0;
     // A pixel's samples are one sequential chain (one RNG stream), so a frame cannot end before its longest pixel does
     // (glass: up to max_depth rays per sample).  One rehearsal of the first samples of every pixel -- the same RNG streams,
     // nothing written but ray counts, cost probe_spp / spp of the frame -- serves two schedulers:
@@ -413,10 +419,10 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     //    launch skips them.  C2 took 367 ms where its throughput alone needs ~310; 338 ms with the two launches.
     // Every pixel is still rendered exactly once from its own stream: the frame is the same bit for bit
     // (tests: ...tile_ranking..., ...heavy_and_light...; RT_FLAG_ROW_MAJOR_TILES / RT_FLAG_NO_PIXEL_CLASSES turn them off).
-    const bool bvh_kernel = f.last_kernel.kind < 8;
+    const bool bvh_kernel = (f.last_kernel.kind & 63) < 8;
     bool rank_tiles = bvh_kernel && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 && !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
     if (const char *e = std::getenv("RTOW_TILE_SORT")) rank_tiles = rank_tiles && std::atoi(e) != 0;  // experiments only
-    const bool list_kernel = f.last_kernel.kind >= 16, prim_bvh_kernel = f.last_kernel.kind == 0;
+    const bool list_kernel = (f.last_kernel.kind & 63) >= 16 && (f.last_kernel.kind & 63) < 32, prim_bvh_kernel = (f.last_kernel.kind & 63) == 0;
     bool split = (list_kernel || prim_bvh_kernel) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
                  f.n_pixels >= 65536u && p->pixels_per_wave <= 0 && !std::getenv("RTOW_PIXELS_PER_WAVE");
     if (const char *e = std::getenv("RTOW_PIXEL_CLASSES")) split = split && std::atoi(e) != 0;  // experiments only
@@ -450,7 +456,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
         }
         HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, (light) queue cursor
         if (split) {
-            int heavy_rays_per_sample = 10, heavy_ppw = list_kernel ? 4 : 16, heavy_blocks = f.num_cus, heavy_prio = list_kernel ? 0 : 2;
+            int heavy_rays_per_sample = 10, heavy_ppw = list_kernel ? 4 : 16, heavy_blocks = list_kernel ? f.num_cus / 2 : f.num_cus, heavy_prio = list_kernel ? 0 : 2;
             if (const char *e = std::getenv("RTOW_HEAVY_RAYS")) heavy_rays_per_sample = std::atoi(e);  // experiments only, all four
             if (const char *e = std::getenv("RTOW_HEAVY_PPW")) heavy_ppw = std::atoi(e);
             if (const char *e = std::getenv("RTOW_HEAVY_BLOCKS")) heavy_blocks = std::atoi(e);

@@ -98,6 +98,21 @@ constexpr uint32_t kTreeObjBit = 0x80000000u;  // HitInfo::obj of a hit inside a
 // Bottom node (span 1 or 2, R/BvhNode.h:63-72): a, b = leaf refs (a == b for span 1).
 struct BvhNodeRec { double xlo, xhi, ylo, yhi, zlo, zhi; uint32_t a, b, escape, pad; };
 
+// The library's own tree for BVH worlds of primitives only.  Such a world's closest hit does not depend on how it is
+// searched (no leaf draws random numbers: the reference's BVH == list invariant, Docs 2-3 BVH :733,:772), so instead of
+// the reference's median-split tree in its fixed visiting order (36 node visits and 5 leaf tests per ray on the random-
+// spheres scene) the kernel may walk a surface-area-heuristic tree near child first.  Still a stackless walk over a flat
+// array: every node carries, for each of the eight sign octants of the ray direction, the node to go to when its box is hit
+// (the near child) and when it is not / when its subtree is done (the escape) -- the near-first order depends only on
+// the octant.  88 bytes: the box, two leaf refs (bottom nodes hold one or two primitives; a = REF_INNER marker otherwise),
+// 8 x {hit, escape} as 16-bit node indices (0xFFFF = the walk is over).
+struct FastNodeRec {
+    double xlo, xhi, ylo, yhi, zlo, zhi;
+    uint32_t a, b;
+    uint16_t link[8][2];
+};
+constexpr uint32_t kFastEnd = 0xFFFFu;
+
 // Materials (R/Material.h, R/Metal.h, R/Dielectric.h)
 enum : uint32_t { MAT_LAMBERTIAN = 0u, MAT_METAL = 1u, MAT_DIELECTRIC = 2u, MAT_DIFFUSE_LIGHT = 3u, MAT_ISOTROPIC = 4u };
 // metal: rgb + fuzz; dielectric: p = ior.
@@ -142,6 +157,8 @@ struct DeviceScene {
     const MediumRec *media;
     const GroupBox *group_boxes;
     const BvhNodeRec *nodes;
+    const FastNodeRec *fast_nodes;  // nullptr unless the world is a BVH of primitives only (see FastNodeRec)
+    uint32_t n_fast_nodes;
     const TreeNodeRec *tree_nodes;
     const uint32_t *tree_items;   // children of TN_LIST nodes (tree node indices)
     const BvhNodeRec *tree_bvh;   // threaded nodes of the BvhNodes inside trees (a table of their own: nodes[] starts with the world's)

@@ -51,9 +51,11 @@ namespace {
 //   BLOCK      threads per workgroup.  256 (four waves) everywhere except the deep general kernel, which runs ONE workgroup of
 //              768 threads per CU -- three waves per SIMD as before, but one copy of the scene tables in the CU's 160 KB of LDS
 //              instead of three in 52 KB each: besides the node rows, the box rows and the sphere table fit as well
+//   FAST       primitive-only BVH world walked through the library's own SAH tree, near child first (flat_scene.h FastNodeRec)
 template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false, bool NESTED_ = false,
-          int BLOCK_ = 256>
+          int BLOCK_ = 256, bool FAST_ = false>
 struct Traits {
+    static constexpr bool FAST = FAST_ && !COMPOSITE_ && WORLD_ == 0;
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool NESTED = NESTED_ && COMPOSITE_;
     static constexpr bool BATCH = BATCH_ && COMPOSITE_ && WORLD_ == 0;
@@ -93,6 +95,7 @@ struct NodeView {
 };
 
 #define DEV __device__ __forceinline__
+#define RT_LDS __attribute__((address_space(3)))  // pointers typed for LDS: loads through them are ds_read, never flat
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -146,7 +149,7 @@ DEV MediumRec get_medium(const DeviceScene &sc, uint32_t i) { return sc.lds_medi
 DEV bool material_needs_uv(const DeviceScene &sc, uint32_t i)
 {
     if (sc.lds_materials != kNone)
-        return *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_materials + i * (uint32_t)sizeof(MaterialRec) + (uint32_t)offsetof(MaterialRec, needs_uv)) != 0;
+        return *(const RT_LDS uint32_t *)(lds_raw + sc.lds_materials + i * (uint32_t)sizeof(MaterialRec) + (uint32_t)offsetof(MaterialRec, needs_uv)) != 0;
     return sc.materials[i].needs_uv != 0;
 }
 
@@ -878,11 +881,13 @@ struct Walk {
     //           are tested in the next leaf phase;
     //   done    (kNone): the walk is complete (or no walk is in progress).
     uint32_t state;
+    uint32_t oct_off;  // FAST kernels: byte offset, inside a FastNodeRec row, of the link pair of this ray's direction octant
     bool any;
 };
 
 DEV void walk_begin(Walk &w, const Ray &r, double tmax)
 {
+    w.oct_off = 56u + 4u * ((r.d.x < 0.0 ? 1u : 0u) | (r.d.y < 0.0 ? 2u : 0u) | (r.d.z < 0.0 ? 4u : 0u));
     w.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     w.a = dot(r.d, r.d);
     w.closest = tmax;
@@ -890,7 +895,11 @@ DEV void walk_begin(Walk &w, const Ray &r, double tmax)
     w.any = false;
 }
 
+DEV uint32_t leaf_kind(uint32_t ref);
+constexpr uint32_t kWalkKindShift = 28;  // kind-batched kernels: bits 28-29 of a parked state = kind of the pending leaf
+
 // One inner-node step: box test, then descend / escape; a bottom node whose box is hit parks the lane.
+template <bool BATCH = false>
 DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
 {
     const uint32_t n = w.state;
@@ -908,7 +917,9 @@ DEV void walk_node(const NodeView &nv, const Ray &r, double tmin, Walk &w)
     // selects, not branches: hit an inner node -> its first child; hit a bottom node -> park on it until the leaf phase;
     // missed -> the escape link
     const bool hit = box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
-    const uint32_t down = (na >> kRefShift) == REF_INNER ? n + 1u : (n | kWalkParked);
+    uint32_t park = n | kWalkParked;
+    if constexpr (BATCH) park |= leaf_kind(na) << kWalkKindShift;  // the wave sorts its parked lanes by this, without a table read
+    const uint32_t down = (na >> kRefShift) == REF_INNER ? n + 1u : park;
     w.state = hit ? down : next;
 }
 
@@ -964,6 +975,69 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
     w.state = next;
 }
 
+// ---- the library's own tree (FastNodeRec): same resumable walk, 88-byte rows, links chosen by the ray's octant ----
+constexpr uint32_t kFastNodeBytes = (uint32_t)sizeof(FastNodeRec);
+static_assert(sizeof(FastNodeRec) == 88, "row layout: box 48, leaf refs 8, links 32");
+// The rows are only ever read from LDS (the launcher falls back to the reference-tree kernel when they do not fit): a
+// branch between an LDS and a global copy made the compiler merge the two into generic pointers and flat loads.
+[[maybe_unused]] constexpr uint32_t kFastLdsBudget = 60 * 1024;
+DEV void walk_node_fast(const Ray &r, double tmin, Walk &w)
+{
+    const uint32_t n = w.state;
+    const uint32_t base = __umul24(n, kFastNodeBytes);
+    const double xlo = *reinterpret_cast<const double *>(lds_raw + base), xhi = *reinterpret_cast<const double *>(lds_raw + base + 8u);
+    const double ylo = *reinterpret_cast<const double *>(lds_raw + base + 16u), yhi = *reinterpret_cast<const double *>(lds_raw + base + 24u);
+    const double zlo = *reinterpret_cast<const double *>(lds_raw + base + 32u), zhi = *reinterpret_cast<const double *>(lds_raw + base + 40u);
+    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 48u);
+    const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
+    const bool hit = box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
+    const uint32_t first = links & 0xFFFFu, esc = links >> 16;
+    const uint32_t down = (na >> kRefShift) == REF_INNER ? first : (n | kWalkParked);
+    const uint32_t next = esc == kFastEnd ? kNone : esc;
+    w.state = hit ? down : next;
+}
+DEV void walk_leaves_fast(const DeviceScene &sc, const Ray &r, double tmin, Walk &w, HitInfo &best)
+{
+    const uint32_t n = w.state & ~kWalkParked;
+    const uint32_t base = __umul24(n, kFastNodeBytes);
+    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 48u);
+    const uint32_t nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 52u);
+    const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
+    const uint32_t esc = links >> 16;
+    const uint32_t next = esc == kFastEnd ? kNone : esc;
+    if ((na >> kRefShift) == REF_MSPHERE && nb != kNone && (nb >> kRefShift) == REF_MSPHERE) {  // both rows in one round trip
+        const bool unit_time = (sc.flags & SCENE_MS_UNIT_TIME) != 0;
+        const MSphereGeom ga = sc.mspheres[na & kRefIndexMask], gb = sc.mspheres[nb & kRefIndexMask];
+        double t;
+        if (sphere_test(r.o - msphere_center(ga, r.tm, unit_time), r.d, w.a, ga.r2, tmin, w.closest, t)) {
+            w.any = true; w.closest = t; best.t = t; best.ref = na; best.obj = kNone;
+        }
+        if (sphere_test(r.o - msphere_center(gb, r.tm, unit_time), r.d, w.a, gb.r2, tmin, w.closest, t)) {
+            w.any = true; w.closest = t; best.t = t; best.ref = nb; best.obj = kNone;
+        }
+        w.state = next;
+        return;
+    }
+    if ((na >> kRefShift) == REF_MSPHERE && nb == kNone) {  // a bottom node of one sphere row
+        const MSphereGeom ga = sc.mspheres[na & kRefIndexMask];
+        double t;
+        if (sphere_test(r.o - msphere_center(ga, r.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0), r.d, w.a, ga.r2, tmin, w.closest, t)) {
+            w.any = true; w.closest = t; best.t = t; best.ref = na; best.obj = kNone;
+        }
+        w.state = next;
+        return;
+    }
+    for (int c = 0; c < 2; c++) {  // one inlined copy of the test
+        const uint32_t ref = c ? nb : na;
+        if (ref == kNone) break;
+        double t;
+        if (prim_test(sc, ref, r, w.a, tmin, w.closest, t)) {
+            w.any = true; w.closest = t; best.t = t; best.ref = ref; best.obj = kNone;
+        }
+    }
+    w.state = next;
+}
+
 // Composite worlds: the leaf phase runs one KIND of leaf at a time.  A box, a medium, an instance and a plain primitive
 // are four different pieces of code; tested in one divergent pass the wave executes each of them with the few lanes
 // that happen to stand on that kind (measured on the Book-2 final scene: 12-16 of 64 lanes per pass).  So a parked
@@ -973,7 +1047,7 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
 // executes them changes -- so the RNG draws of media are consumed exactly as before.
 enum : uint32_t { LK_BOX = 0u, LK_MEDIUM = 1u, LK_OBJECT = 2u, LK_PRIM = 3u };
 constexpr uint32_t kWalkSecond = 0x40000000u;  // parked on the bottom node's SECOND leaf
-constexpr uint32_t kWalkNodeMask = 0x3FFFFFFFu;
+constexpr uint32_t kWalkNodeMask = 0x0FFFFFFFu;
 DEV uint32_t leaf_kind(uint32_t ref)
 {
     const uint32_t tag = ref >> kRefShift;
@@ -1055,7 +1129,7 @@ DEV void walk_leaf_pass(const DeviceScene &sc, const NodeView &nv, const Ray &r,
             break;
         }
         if (leaf_kind(nb) != K) {
-            w.state |= kWalkSecond;
+            w.state = (w.state & ~(3u << kWalkKindShift)) | kWalkSecond | (leaf_kind(nb) << kWalkKindShift);
             break;
         }
         second = true;
@@ -1790,21 +1864,27 @@ DEV Vec texture_value(const DeviceScene &sc, uint32_t ti, double u, double v, Ve
 struct MatView {
     const MaterialRec *global;
     uint32_t lds_off;  // byte offset of the row in LDS, or kNone
+    // The LDS side is read through a pointer typed for the LDS address space: two loads through generic pointers get merged
+    // into one flat load through a selected pointer (slower than ds_read, and it ties up both wait counters).
     DEV double f64(uint32_t off) const
     {
-        if (lds_off != kNone) return *reinterpret_cast<const double *>(lds_raw + lds_off + off);
+        if (lds_off != kNone) return *(const RT_LDS double *)(lds_raw + lds_off + off);
         return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(global) + off);
     }
     DEV uint32_t u32(uint32_t off) const
     {
-        if (lds_off != kNone) return *reinterpret_cast<const uint32_t *>(lds_raw + lds_off + off);
+        if (lds_off != kNone) return *(const RT_LDS uint32_t *)(lds_raw + lds_off + off);
         return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(global) + off);
     }
     DEV Vec vec(uint32_t off) const { return mk(f64(off), f64(off + 8u), f64(off + 16u)); }
 };
 #define MAT_OFF(field) ((uint32_t)offsetof(MaterialRec, field))
+// MAY_BE_STAGED = false (kernels that never stage materials): the LDS side folds away at compile time -- left in, the
+// compiler merges the two loads of every field into one flat load through a selected pointer
+template <bool MAY_BE_STAGED>
 DEV MatView material_view(const DeviceScene &sc, uint32_t i)
 {
+    if constexpr (!MAY_BE_STAGED) return MatView{sc.materials + i, kNone};
     return MatView{sc.materials + i, sc.lds_materials != kNone ? sc.lds_materials + i * (uint32_t)sizeof(MaterialRec) : kNone};
 }
 
@@ -1854,7 +1934,7 @@ template <class T>
 DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughput, Vec &accumulated, Xorwow &rng)
 {
     // only the fields a material kind needs are loaded (the row is 112 bytes)
-    const MatView mp = material_view(sc, s.mat);
+    const MatView mp = material_view<T::COMPOSITE && T::WORLD == 0>(sc, s.mat);
     struct { uint32_t kind, tex_inline; } m = {mp.u32(MAT_OFF(kind)), mp.u32(MAT_OFF(tex_inline))};
     Vec atten;
     Ray out;
@@ -1974,7 +2054,16 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
         // BVH nodes in LDS, one 72-byte row each (see lds_node_f64 for the layout and why 72)
         nv.global = sc.nodes;
         nv.in_lds = a.lds_nodes != 0;
-        if (nv.in_lds) {
+        if constexpr (T::FAST) {
+            {  // the library's own tree: rows copied as they are (always staged: see walk_node_fast)
+                const uint32_t words = sc.n_fast_nodes * (kFastNodeBytes / 4u);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.fast_nodes);
+                for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) dst[k] = src[k];
+                nv.n = sc.n_fast_nodes;
+                __syncthreads();
+            }
+        } else if (nv.in_lds) {
             const uint32_t n = sc.n_world_nodes;
             for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
                 BvhNodeRec node = sc.nodes[k];
@@ -2192,7 +2281,8 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             // many lanes at once instead of trailing every node visit with a few.
             // node/leaf phase pairs per look at the shading queue: measured optimum 6 for primitive worlds (C3: 8 -> 6 is
             // +7 %, 4 is -1 %), 4 for composite ones (C5: +6 %; C4 indifferent)
-            for (int round = 0; round < (T::COMPOSITE ? kRoundsComposite : kRounds); round++) {
+            const int n_rounds = T::BATCH ? a.rounds : (T::COMPOSITE ? kRoundsComposite : kRounds);
+            for (int round = 0; round < n_rounds; round++) {
                 for (int step = 0; step < (T::COMPOSITE ? a.node_burst : kBurst); step++) {
                     const bool mover = walk_moving(walk.state);
 #if RT_SIMPLE_BREAK
@@ -2207,12 +2297,17 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                     {
                         PH_BEGIN();
                         if (mover) {
-                            walk_node(nv, ray, 0.001, walk);
+                            if constexpr (T::FAST) {
+                                walk_node_fast(ray, 0.001, walk);
+                                if (walk_moving(walk.state)) walk_node_fast(ray, 0.001, walk);
+                            } else
+                            walk_node<T::BATCH>(nv, ray, 0.001, walk);
                             // Primitive worlds (deep BVH, cheap leaves): a second visit before the next look at the
                             // wave's state -- the ballots and counts that steer the phases cost a fifth of a node visit.
                             // Not for composite worlds: the Cornell box's tree is three levels deep (measured -17 %).
-                            if constexpr (!T::COMPOSITE) {
-                                if (walk_moving(walk.state)) walk_node(nv, ray, 0.001, walk);
+                            // Kind-batched kernels run on deep trees too: the same second visit (C5 +x %).
+                            if constexpr ((!T::COMPOSITE || T::BATCH) && !T::FAST) {
+                                if (walk_moving(walk.state)) walk_node<T::BATCH>(nv, ray, 0.001, walk);
                             }
                         }
                         PH_END(0, mover);
@@ -2221,17 +2316,17 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                 if constexpr (T::BATCH) {
                     const bool at_leaf = walk_parked(walk.state);
                     if (__any(at_leaf)) {
-                        const uint32_t pending = at_leaf ? walk_pending_leaf(nv, walk.state) : kNone;
-                        const uint32_t kind = leaf_kind(pending);
+                        const uint32_t kind = (walk.state >> kWalkKindShift) & 3u;  // of the pending leaf (walk_node, walk_leaf_pass)
                         // everything is served in the last round before shading is looked at again, and when nobody walks
-                        const bool serve_all = round + 1 == kRoundsComposite || !__any(walk_moving(walk.state));
+                        const bool serve_all = round + 1 == n_rounds || !__any(walk_moving(walk.state));
 #define RT_LEAF_PASS(K, SLOT)                                                                                          \
                         {                                                                                              \
                             const bool mine = at_leaf && kind == (K);                                                  \
                             const int waiting = __popcll(__ballot(mine));                                              \
                             if (waiting > 0 && (serve_all || waiting >= a.leaf_batch)) {                               \
                                 PH_BEGIN();                                                                            \
-                                if (mine) walk_leaf_pass<T, (K)>(sc, nv, ray, 0.001, walk, walk_best, rng, pending PH_PASS); \
+                                if (mine) walk_leaf_pass<T, (K)>(sc, nv, ray, 0.001, walk, walk_best, rng,             \
+                                                                 walk_pending_leaf(nv, walk.state) PH_PASS);           \
                                 PH_END(SLOT, mine);                                                                    \
                             }                                                                                          \
                         }
@@ -2242,7 +2337,8 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                             const int waiting = __popcll(__ballot(mine));
                             if (waiting > 0 && (serve_all || waiting >= a.object_batch)) {
                                 PH_BEGIN();
-                                walk_object_pass<T>(sc, nv, ray, 0.001, walk, walk_best, rng, pending, mine, lane PH_PASS);
+                                walk_object_pass<T>(sc, nv, ray, 0.001, walk, walk_best, rng,
+                                                    mine ? walk_pending_leaf(nv, walk.state) : kNone, mine, lane PH_PASS);
                                 PH_END(18, mine);
                             }
                         }
@@ -2253,7 +2349,8 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                     const bool at_leaf = walk_parked(walk.state);
                     PH_BEGIN();
                     if (at_leaf) {
-                        walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng PH_PASS);
+                        if constexpr (T::FAST) walk_leaves_fast(sc, ray, 0.001, walk, walk_best);
+                        else walk_leaves<T>(sc, nv, ray, 0.001, walk, walk_best, rng PH_PASS);
                     }
                     if (__any(at_leaf)) PH_END(1, at_leaf);
                 }
@@ -2489,6 +2586,7 @@ namespace {
 #endif
 using TSphereList = Traits<2, false, false, RT_WAVES_SPHERES>;
 using TBvhPrims = Traits<0, false, false, RT_WAVES_BVH>;
+using TBvhPrimsFast = Traits<0, false, false, RT_WAVES_BVH, false, false, false, 256, true>;  // through the library's own tree
 #ifndef RT_WAVES_GENERAL
 #define RT_WAVES_GENERAL 2
 #endif
@@ -2532,7 +2630,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
     size_t lds = 0;
     a.lds_nodes = 0;
     if (T::WORLD == 0) {
-        size_t need = (size_t)sc.n_world_nodes * kLdsNodeBytes;
+        size_t need = T::FAST ? (size_t)sc.n_fast_nodes * kFastNodeBytes : (size_t)sc.n_world_nodes * kLdsNodeBytes;
         if (need <= 60 * 1024) {  // keep >= 2 workgroups (of 256 threads) per CU resident
             lds = need;
             a.lds_nodes = 1;
@@ -2581,7 +2679,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
         if (e != hipSuccess) return e;
         info->vgprs = attr.numRegs;
         info->lds_bytes = (int)(attr.sharedSizeBytes + lds);
-        info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0) + (T::NESTED ? 32 : 0);
+        info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0) + (T::NESTED ? 32 : 0) + (T::FAST ? 64 : 0);
         return hipSuccess;
     }
     if (a.n_pixels == 0 || a.spp <= 0) return hipSuccess;
@@ -2645,7 +2743,10 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
     const bool scan_world = sc.world_kind == WORLD_LIST || (sc.n_world_items <= 16u && sc.scan_cost <= (uint32_t)a.small_world && !a.always_walk);
     if (scan_world && !rich && !media && !a.force_general) return composite_kernel(composite ? CK_LIST_INSTANCES : CK_LIST_PRIMS);
     if (sc.world_kind == WORLD_BVH) {
-        if (!composite && !rich && !a.force_general) return launch_one<TBvhPrims>(sc, a, stream, info);
+        if (!composite && !rich && !a.force_general)
+            return (sc.fast_nodes && !a.reference_tree && sc.n_fast_nodes * kFastNodeBytes <= kFastLdsBudget)
+                       ? launch_one<TBvhPrimsFast>(sc, a, stream, info)
+                       : launch_one<TBvhPrims>(sc, a, stream, info);
         if (!rich && !a.force_general) return composite_kernel(media ? CK_BVH_MEDIA : CK_BVH_INSTANCES);
         return composite_kernel(sc.n_world_nodes > 64 ? CK_BVH_GENERAL_DEEP : CK_BVH_GENERAL);
     }

@@ -45,9 +45,11 @@ struct RenderArgs {
     int32_t node_burst;     // composite BVH worlds: node visits between two leaf phases (set by the launcher)
     int32_t park_ratio;     // composite BVH worlds: the leaf phase starts once parked lanes outnumber moving ones by this factor
     int32_t leaf_batch;     // composite BVH worlds: a kind of leaf is tested once this many lanes of the wave wait for it
+    int32_t rounds;         // kind-batched kernels: node / leaf rounds per look at the shading queue
     int32_t object_batch;   // the same for instances / groups (their cooperative scan serves one ray at a time: a small batch is fine)
     int32_t lds_nodes;      // set by the launcher: BVH nodes are staged in LDS
     int32_t small_world;    // BVH worlds without media are scanned, not walked, up to this scan cost (and 16 leaves)
+    int32_t reference_tree; // primitive BVH worlds: walk the reference's own tree in its own order (default: the library's SAH tree)
     int32_t always_walk;    // BVH worlds: walk the tree even where a scan of all leaves would be used (small scenes)
     int32_t force_general;  // tests: use the general kernel even where a specialised one applies
     int32_t coop_threshold; // sphere-list kernel: below this many live lanes a wave scans cooperatively

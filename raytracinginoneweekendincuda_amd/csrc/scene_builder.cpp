@@ -6,6 +6,7 @@
 // that decides geometry (bounding boxes, quad planes, rotation constants, BVH split order) follows
 // the reference expression by expression, in fp64 without contraction, so the tables are bit-identical
 // to what the reference's constructors compute.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -729,6 +730,131 @@ static void lower_materials(SceneImpl &s, FlatScene &f)
     f.perlin = s.perlin;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The library's own tree for primitive-only BVH worlds (flat_scene.h FastNodeRec): surface-area heuristic, full sweep
+// over the three axes, bottom nodes of one or two primitives; then the eight octant threadings.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct FastBuilder {
+    const std::vector<Box> &boxes;       // the primitives' own boxes (the reference's, padded where thin)
+    const std::vector<uint32_t> &refs;   // their leaf refs
+    struct Node {
+        Box box;
+        int left = -1, right = -1;       // children, or -1
+        uint32_t a = kNone, b = kNone;   // bottom node: one or two leaf refs
+        int axis = 0;
+    };
+    std::vector<Node> nodes;
+
+    static double area(const Box &b)
+    {
+        const double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+    int build(std::vector<uint32_t> &idx, size_t lo, size_t hi)
+    {
+        const int me = (int)nodes.size();
+        nodes.push_back({});
+        Node node;
+        node.box = empty_box();
+        for (size_t k = lo; k < hi; k++) node.box = box_merge(node.box, boxes[idx[k]]);
+        const size_t n = hi - lo;
+        if (n <= 2) {
+            node.a = refs[idx[lo]];
+            if (n == 2) node.b = refs[idx[lo + 1]];
+            nodes[me] = node;
+            return me;
+        }
+        // best split over the three axes: sort by box centre, sweep prefix / suffix areas
+        double best_cost = DBL_MAX;
+        int best_axis = 0;
+        size_t best_at = lo + n / 2;
+        std::vector<uint32_t> order(idx.begin() + lo, idx.begin() + hi), best_order;
+        std::vector<double> suffix(n + 1);
+        for (int axis = 0; axis < 3; axis++) {
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t p, uint32_t q) {
+                return boxes[p].lo[axis] + boxes[p].hi[axis] < boxes[q].lo[axis] + boxes[q].hi[axis];
+            });
+            Box acc = empty_box();
+            suffix[n] = 0.0;
+            for (size_t k = n; k-- > 0;) {
+                acc = box_merge(acc, boxes[order[k]]);
+                suffix[k] = area(acc);
+            }
+            acc = empty_box();
+            for (size_t k = 1; k < n; k++) {
+                acc = box_merge(acc, boxes[order[k - 1]]);
+                const double cost = area(acc) * (double)k + suffix[k] * (double)(n - k);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_at = lo + k;
+                    best_order = order;
+                }
+            }
+        }
+        std::copy(best_order.begin(), best_order.end(), idx.begin() + lo);
+        node.axis = best_axis;
+        node.left = build(idx, lo, best_at);
+        node.right = build(idx, best_at, hi);
+        nodes[me] = node;
+        return me;
+    }
+    // visiting order for direction octant `oct` (bit k set: direction component k is negative): the child on the side
+    // the ray comes from first.  hit[n] = where to go when n's box is hit (inner nodes), esc[n] = where to go otherwise.
+    void thread(int n, uint32_t escape, int oct, std::vector<uint16_t> &hit, std::vector<uint16_t> &esc) const
+    {
+        const Node &nd = nodes[n];
+        esc[n] = (uint16_t)escape;
+        if (nd.left < 0) {
+            hit[n] = (uint16_t)escape;  // unused: a bottom node parks the lane; its leaves done, the walk goes to esc
+            return;
+        }
+        const bool negative = (oct >> nd.axis) & 1;
+        const int first = negative ? nd.right : nd.left, second = negative ? nd.left : nd.right;
+        hit[n] = (uint16_t)first;
+        thread(first, (uint32_t)second, oct, hit, esc);
+        thread(second, escape, oct, hit, esc);
+    }
+};
+} // namespace
+
+static void build_fast_tree(FlatScene &f)
+{
+    f.fast_nodes.clear();
+    const size_t n = f.world_items.size();
+    if (f.world_kind != WORLD_BVH || n < 3 || n > 40000 || !f.objects.empty() || !f.boxes.empty() || !f.tree_nodes.empty()) return;
+    for (uint32_t ref : f.world_items) {
+        const uint32_t tag = ref >> kRefShift;
+        if (tag != REF_SPHERE && tag != REF_MSPHERE && tag != REF_QUAD) return;
+    }
+    if (const char *e = std::getenv("RTOW_REFERENCE_TREE"))  // A/B experiments: keep the reference's tree only
+        if (std::atoi(e) != 0) return;
+    FastBuilder fb{f.leaf_boxes, f.world_items, {}};
+    std::vector<uint32_t> idx(n);
+    for (size_t k = 0; k < n; k++) idx[k] = (uint32_t)k;
+    fb.build(idx, 0, n);
+    if (fb.nodes.size() >= kFastEnd) return;
+    f.fast_nodes.resize(fb.nodes.size());
+    for (size_t k = 0; k < fb.nodes.size(); k++) {
+        const FastBuilder::Node &nd = fb.nodes[k];
+        FastNodeRec &r = f.fast_nodes[k];
+        r.xlo = nd.box.lo[0]; r.xhi = nd.box.hi[0];
+        r.ylo = nd.box.lo[1]; r.yhi = nd.box.hi[1];
+        r.zlo = nd.box.lo[2]; r.zhi = nd.box.hi[2];
+        r.a = nd.left < 0 ? nd.a : make_ref(REF_INNER, 0);
+        r.b = nd.left < 0 ? nd.b : make_ref(REF_INNER, 0);
+    }
+    std::vector<uint16_t> hit(fb.nodes.size()), esc(fb.nodes.size());
+    for (int oct = 0; oct < 8; oct++) {
+        fb.thread(0, kFastEnd, oct, hit, esc);
+        for (size_t k = 0; k < fb.nodes.size(); k++) {
+            f.fast_nodes[k].link[oct][0] = hit[k];
+            f.fast_nodes[k].link[oct][1] = esc[k];
+        }
+    }
+}
+
 int flatten_scene(SceneImpl &s)
 {
     if (s.world == 0) return fail(RT_ERR_STATE, "rt_scene_commit: no world set (rt_scene_set_world)");
@@ -825,6 +951,7 @@ int flatten_scene(SceneImpl &s)
         }
         f.scan_cost = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
     }
+    build_fast_tree(f);
     {
         bool unit_time = !f.mspheres.empty();
         for (const MSphereGeom &m : f.mspheres) unit_time &= (m.t0 == 0.0 && m.dt == 1.0);
@@ -1357,6 +1484,25 @@ int rt_scene_dump_nodes(rt_scene *s, int max_nodes, double *box_out, uint32_t *a
             abe_out[3 * k + 1] = r.b;
             abe_out[3 * k + 2] = r.escape;
         }
+    }
+    return n;
+}
+int rt_scene_dump_fast_nodes(rt_scene *s, int max_nodes, double *box_out, uint32_t *ab_out, uint16_t *link_out)
+{
+    if (!s || !S(s)->committed) return -fail(RT_ERR_STATE, "rt_scene_dump_fast_nodes: scene not committed");
+    const FlatScene &f = S(s)->flat;
+    int n = (int)f.fast_nodes.size();
+    for (int k = 0; k < n && k < max_nodes; k++) {
+        const FastNodeRec &r = f.fast_nodes[k];
+        if (box_out) {
+            double *b = box_out + 6 * k;
+            b[0] = r.xlo; b[1] = r.xhi; b[2] = r.ylo; b[3] = r.yhi; b[4] = r.zlo; b[5] = r.zhi;
+        }
+        if (ab_out) {
+            ab_out[2 * k] = r.a;
+            ab_out[2 * k + 1] = r.b;
+        }
+        if (link_out) std::memcpy(link_out + 16 * k, r.link, sizeof r.link);
     }
     return n;
 }

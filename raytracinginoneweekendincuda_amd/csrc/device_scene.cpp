@@ -208,6 +208,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_perlin = (uint32_t)f.perlin.size();
     d.n_group_boxes = (uint32_t)f.group_boxes.size();
     d.lds_quad_aa = d.lds_boxes = d.lds_objects = d.lds_xforms = d.lds_media = d.lds_materials = d.lds_perlin = d.lds_spheres_tab = d.lds_group_boxes = kNone;
+    d.lds_mspheres = d.lds_msphere_aux = d.lds_sphere_aux = kNone;
     d.flags = f.flags;
     s.device[device] = dt;
     return RT_OK;

@@ -184,7 +184,8 @@ struct DeviceScene {
     // Tables a leaf test or the shading chases through -- object record -> transforms -> box / quad rows, medium rows,
     // material rows, Perlin tables -- are staged in LDS behind the node rows where they fit.  Byte offsets into the
     // dynamic LDS block, set by the launcher per table; kNone = read the global table.
-    uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin, lds_spheres_tab, lds_group_boxes;
+    uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin, lds_spheres_tab, lds_group_boxes,
+        lds_mspheres, lds_msphere_aux, lds_sphere_aux;  // the primitive tables of a sphere world (library-tree kernel, one workgroup per CU)
     uint32_t flags;
 };
 

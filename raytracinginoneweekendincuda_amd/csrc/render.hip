@@ -139,6 +139,25 @@ DEV R const_row(const R *table, uint32_t i)
     for (uint32_t k = 0; k < sizeof(R) / 8; k++) u.w[k] = src[k];
     return u.row;
 }
+// The same through a pointer typed for the LDS address space, for call sites that choose between the LDS copy and the global
+// table at run time: two loads through generic pointers get merged into one flat load through a selected pointer.
+template <class R>
+DEV R lds_row_typed(uint32_t byte_off, uint32_t idx)
+{
+    static_assert(sizeof(R) % 8 == 0, "rows are whole quadwords");
+    const RT_LDS uint64_t *src = (const RT_LDS uint64_t *)(lds_raw + byte_off + idx * (uint32_t)sizeof(R));
+    union {
+        R row;
+        uint64_t w[sizeof(R) / 8];
+    } u;
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(R) / 8; k++) u.w[k] = src[k];
+    return u.row;
+}
+DEV MSphereGeom get_msphere(const DeviceScene &sc, uint32_t i) { return sc.lds_mspheres != kNone ? lds_row_typed<MSphereGeom>(sc.lds_mspheres, i) : sc.mspheres[i]; }
+DEV SphereAux get_msphere_aux(const DeviceScene &sc, uint32_t i) { return sc.lds_msphere_aux != kNone ? lds_row_typed<SphereAux>(sc.lds_msphere_aux, i) : sc.msphere_aux[i]; }
+DEV SphereAux get_sphere_aux(const DeviceScene &sc, uint32_t i) { return sc.lds_sphere_aux != kNone ? lds_row_typed<SphereAux>(sc.lds_sphere_aux, i) : sc.sphere_aux[i]; }
+DEV SphereGeom get_sphere_typed(const DeviceScene &sc, uint32_t i) { return sc.lds_spheres_tab != kNone ? lds_row_typed<SphereGeom>(sc.lds_spheres_tab, i) : sc.spheres[i]; }
 DEV AAQuad get_quad_aa(const DeviceScene &sc, uint32_t i) { return sc.lds_quad_aa != kNone ? lds_row<AAQuad>(sc.lds_quad_aa, i) : const_row(sc.quad_aa, i); }
 DEV BoxRec get_box(const DeviceScene &sc, uint32_t i) { return sc.lds_boxes != kNone ? lds_row<BoxRec>(sc.lds_boxes, i) : const_row(sc.boxes, i); }
 DEV ObjectRec get_object(const DeviceScene &sc, uint32_t i) { return sc.lds_objects != kNone ? lds_row<ObjectRec>(sc.lds_objects, i) : const_row(sc.objects, i); }
@@ -1007,7 +1026,7 @@ DEV void walk_leaves_fast(const DeviceScene &sc, const Ray &r, double tmin, Walk
     const uint32_t next = esc == kFastEnd ? kNone : esc;
     if ((na >> kRefShift) == REF_MSPHERE && nb != kNone && (nb >> kRefShift) == REF_MSPHERE) {  // both rows in one round trip
         const bool unit_time = (sc.flags & SCENE_MS_UNIT_TIME) != 0;
-        const MSphereGeom ga = sc.mspheres[na & kRefIndexMask], gb = sc.mspheres[nb & kRefIndexMask];
+        const MSphereGeom ga = get_msphere(sc, na & kRefIndexMask), gb = get_msphere(sc, nb & kRefIndexMask);
         double t;
         if (sphere_test(r.o - msphere_center(ga, r.tm, unit_time), r.d, w.a, ga.r2, tmin, w.closest, t)) {
             w.any = true; w.closest = t; best.t = t; best.ref = na; best.obj = kNone;
@@ -1019,7 +1038,7 @@ DEV void walk_leaves_fast(const DeviceScene &sc, const Ray &r, double tmin, Walk
         return;
     }
     if ((na >> kRefShift) == REF_MSPHERE && nb == kNone) {  // a bottom node of one sphere row
-        const MSphereGeom ga = sc.mspheres[na & kRefIndexMask];
+        const MSphereGeom ga = get_msphere(sc, na & kRefIndexMask);
         double t;
         if (sphere_test(r.o - msphere_center(ga, r.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0), r.d, w.a, ga.r2, tmin, w.closest, t)) {
             w.any = true; w.closest = t; best.t = t; best.ref = na; best.obj = kNone;
@@ -1730,12 +1749,12 @@ DEV Surface make_surface(const DeviceScene &sc, const Ray &r, const HitInfo &h)
         Vec c;
         SphereAux aux;
         if (T::WORLD == 2 || tag == REF_SPHERE) {
-            SphereGeom g = T::COMPOSITE ? get_sphere(sc, idx) : sc.spheres[idx];
+            SphereGeom g = T::COMPOSITE ? get_sphere(sc, idx) : (T::FAST ? get_sphere_typed(sc, idx) : sc.spheres[idx]);
             c = mk(g.cx, g.cy, g.cz);
-            aux = sc.sphere_aux[idx];
+            aux = T::FAST ? get_sphere_aux(sc, idx) : sc.sphere_aux[idx];
         } else {
-            c = msphere_center(sc.mspheres[idx], lr.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0);
-            aux = sc.msphere_aux[idx];
+            c = msphere_center(T::FAST ? get_msphere(sc, idx) : sc.mspheres[idx], lr.tm, (sc.flags & SCENE_MS_UNIT_TIME) != 0);
+            aux = T::FAST ? get_msphere_aux(sc, idx) : sc.msphere_aux[idx];
         }
         Vec on = aux.inv_r * (s.p - c);
         face(s, lr, on);
@@ -1934,7 +1953,7 @@ template <class T>
 DEV bool shade(const DeviceScene &sc, const Surface &s, Ray &ray, Vec &throughput, Vec &accumulated, Xorwow &rng)
 {
     // only the fields a material kind needs are loaded (the row is 112 bytes)
-    const MatView mp = material_view<T::COMPOSITE && T::WORLD == 0>(sc, s.mat);
+    const MatView mp = material_view<(T::COMPOSITE && T::WORLD == 0) || T::FAST>(sc, s.mat);
     struct { uint32_t kind, tex_inline; } m = {mp.u32(MAT_OFF(kind)), mp.u32(MAT_OFF(tex_inline))};
     Vec atten;
     Ray out;
@@ -2061,6 +2080,17 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.fast_nodes);
                 for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) dst[k] = src[k];
                 nv.n = sc.n_fast_nodes;
+                auto stage = [](uint32_t off, const void *table, uint32_t bytes) {
+                    if (off == kNone) return;
+                    uint32_t *d2 = reinterpret_cast<uint32_t *>(lds_raw + off);
+                    const uint32_t *s2 = static_cast<const uint32_t *>(table);
+                    for (uint32_t w = threadIdx.x; w < bytes / 4u; w += blockDim.x) d2[w] = s2[w];
+                };
+                stage(sc.lds_mspheres, sc.mspheres, sc.n_mspheres * (uint32_t)sizeof(MSphereGeom));
+                stage(sc.lds_msphere_aux, sc.msphere_aux, sc.n_mspheres * (uint32_t)sizeof(SphereAux));
+                stage(sc.lds_spheres_tab, sc.spheres, sc.n_spheres * (uint32_t)sizeof(SphereGeom));
+                stage(sc.lds_sphere_aux, sc.sphere_aux, sc.n_spheres * (uint32_t)sizeof(SphereAux));
+                stage(sc.lds_materials, sc.materials, sc.n_materials * (uint32_t)sizeof(MaterialRec));
                 __syncthreads();
             }
         } else if (nv.in_lds) {
@@ -2586,7 +2616,10 @@ namespace {
 #endif
 using TSphereList = Traits<2, false, false, RT_WAVES_SPHERES>;
 using TBvhPrims = Traits<0, false, false, RT_WAVES_BVH>;
-using TBvhPrimsFast = Traits<0, false, false, RT_WAVES_BVH, false, false, false, 256, true>;  // through the library's own tree
+#ifndef RT_BLOCK_FAST
+#define RT_BLOCK_FAST 768
+#endif
+using TBvhPrimsFast = Traits<0, false, false, RT_WAVES_BVH, false, false, false, RT_BLOCK_FAST, true>;  // through the library's own tree
 #ifndef RT_WAVES_GENERAL
 #define RT_WAVES_GENERAL 2
 #endif
@@ -2634,6 +2667,24 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
         if (need <= 60 * 1024) {  // keep >= 2 workgroups (of 256 threads) per CU resident
             lds = need;
             a.lds_nodes = 1;
+        }
+        if (T::FAST && T::BLOCK >= 768 && a.lds_nodes) {
+            // One workgroup per CU: the sphere rows the leaf tests and the hit record read and the material rows follow the
+            // node rows into the CU's LDS -- a frame ends with its longest pixel, and that pixel's chain is made of exactly
+            // these dependent reads (C3: leaf pass 2100 -> ... cycles, shading pass 11000 -> ... cycles).
+            const size_t budget = 158 * 1024;
+            size_t off = (lds + 15) & ~(size_t)15;
+            auto place = [&](uint32_t &slot, size_t bytes) {
+                if (bytes == 0 || off + bytes + 64 > budget) return;
+                slot = (uint32_t)off;
+                off += (bytes + 15) & ~(size_t)15;
+            };
+            place(sc.lds_mspheres, (size_t)sc.n_mspheres * sizeof(MSphereGeom));
+            place(sc.lds_msphere_aux, (size_t)sc.n_mspheres * sizeof(SphereAux));
+            place(sc.lds_spheres_tab, (size_t)sc.n_spheres * sizeof(SphereGeom));
+            place(sc.lds_sphere_aux, (size_t)sc.n_spheres * sizeof(SphereAux));
+            place(sc.lds_materials, (size_t)sc.n_materials * sizeof(MaterialRec));
+            lds = off;
         }
         if (T::COMPOSITE) {
             // Small tables ride along behind the node rows, each on its own merits: the records a leaf test or the shading

@@ -427,7 +427,12 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     bool split = (list_kernel || prim_bvh_kernel) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
                  f.n_pixels >= 65536u && p->pixels_per_wave <= 0 && !std::getenv("RTOW_PIXELS_PER_WAVE");
     if (const char *e = std::getenv("RTOW_PIXEL_CLASSES")) split = split && std::atoi(e) != 0;  // experiments only
-    if (prim_bvh_kernel && !std::getenv("RTOW_PIXEL_CLASSES")) split = false;  // BVH worlds: opt-in until measured
+    // The primitive-BVH kernel on the reference's tree (256-thread workgroups) gained nothing from a second launch (C3
+    // 1672 -> 1100-1200: opt-in); the library-tree kernel, whose 768-thread workgroup fills a CU, serves both classes in
+    // ONE launch, by wave (RenderArgs::heavy_list): C3 2106 -> 2713 Msamples/s.
+    bool roles_in_one_launch = prim_bvh_kernel && (f.last_kernel.kind & 64) != 0;
+    if (prim_bvh_kernel && !roles_in_one_launch && !std::getenv("RTOW_PIXEL_CLASSES")) split = false;
+    if (const char *e = std::getenv("RTOW_ROLES")) roles_in_one_launch = std::atoi(e) != 0;  // experiments only
     if (rank_tiles || split) {
         int probe_spp = split ? 4 : p->samples_per_pixel / 100;
         probe_spp = probe_spp < 1 ? 1 : (probe_spp > 8 ? 8 : probe_spp);
@@ -457,7 +462,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
         }
         HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, (light) queue cursor
         if (split) {
-            int heavy_rays_per_sample = 10, heavy_ppw = list_kernel ? 4 : 16, heavy_blocks = list_kernel ? f.num_cus / 2 : f.num_cus, heavy_prio = list_kernel ? 0 : 2;
+            int heavy_rays_per_sample = list_kernel ? 10 : 12, heavy_ppw = list_kernel ? 4 : 6, heavy_blocks = list_kernel ? f.num_cus / 2 : f.num_cus, heavy_prio = 0;
             if (const char *e = std::getenv("RTOW_HEAVY_RAYS")) heavy_rays_per_sample = std::atoi(e);  // experiments only, all four
             if (const char *e = std::getenv("RTOW_HEAVY_PPW")) heavy_ppw = std::atoi(e);
             if (const char *e = std::getenv("RTOW_HEAVY_BLOCKS")) heavy_blocks = std::atoi(e);
@@ -466,8 +471,21 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
             HIP_TRY(launch_classify_pixels(f.pix_cost, f.n_pixels, (uint32_t)(heavy_rays_per_sample * probe_spp), f.pix_class,
                                            f.heavy_list, f.heavy_count, stream));
             HIP_TRY(hipMemsetAsync(f.ray_counter + 6, 0, sizeof(unsigned long long), stream));  // heavy queue cursor
-            HIP_TRY(hipEventRecord(f.ev_aux[0], stream));
-            HIP_TRY(hipStreamWaitEvent(f.aux_stream, f.ev_aux[0], 0));
+            if (!roles_in_one_launch) {
+                HIP_TRY(hipEventRecord(f.ev_aux[0], stream));
+                HIP_TRY(hipStreamWaitEvent(f.aux_stream, f.ev_aux[0], 0));
+            }
+            if (roles_in_one_launch) {
+                int heavy_waves = 2;
+                if (const char *e = std::getenv("RTOW_HEAVY_WAVES")) heavy_waves = std::atoi(e);  // experiments only
+                ra.heavy_list = f.heavy_list;
+                ra.heavy_count = f.heavy_count;
+                ra.heavy_cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
+                ra.heavy_waves = heavy_waves;
+                ra.heavy_ppw = heavy_ppw;
+                ra.heavy_priority = heavy_prio;
+                ra.pix_class = f.pix_class;
+            } else {
             RenderArgs heavy = ra;
             heavy.tile_order = nullptr;
             heavy.pixel_list = f.heavy_list;
@@ -481,10 +499,11 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
             HIP_TRY(p->variant ? launch_render_fast(ds, heavy, f.aux_stream) : launch_render_strict(ds, heavy, f.aux_stream));
             HIP_TRY(hipEventRecord(f.ev_aux[1], f.aux_stream));
             ra.pix_class = f.pix_class;
+            }
         }
     }
     HIP_TRY(p->variant ? launch_render_fast(ds, ra, stream) : launch_render_strict(ds, ra, stream));
-    if (split) HIP_TRY(hipStreamWaitEvent(stream, f.ev_aux[1], 0));
+    if (split && !roles_in_one_launch) HIP_TRY(hipStreamWaitEvent(stream, f.ev_aux[1], 0));
     HIP_TRY(hipEventRecord(f.ev[2], stream));
     // The counters come home on the film's own stream: a blocking hipMemcpy in rt_render_finish would wait for every
     // other film's frame as well and serialise frames that were launched to overlap.

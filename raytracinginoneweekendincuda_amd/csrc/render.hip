@@ -2157,6 +2157,15 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     else if (a.wave_priority == 3) __builtin_amdgcn_s_setprio(3);
     const CameraRec *__restrict__ cam = sc.camera;
 
+    // this wave's role (wave-uniform): serve the list of heavy pixels first, a few at a time (RenderArgs::heavy_list)
+    bool heavy_mode = a.heavy_list != nullptr && (int)(threadIdx.x >> 6) < a.heavy_waves;
+    bool heavy_dry = false;
+    const uint32_t heavy_total = heavy_mode ? *(const RT_CONST uint32_t *)(uintptr_t)a.heavy_count : 0u;
+    if (heavy_mode) {
+        if (a.heavy_priority == 1) __builtin_amdgcn_s_setprio(1);
+        else if (a.heavy_priority == 2) __builtin_amdgcn_s_setprio(2);
+        else if (a.heavy_priority == 3) __builtin_amdgcn_s_setprio(3);
+    }
     bool active = false, exhausted = false;
     int i = 0, j = 0;
     size_t local = 0;
@@ -2204,32 +2213,38 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             else boost_left = a.boost_rounds;
         }
 
-        if (!exhausted && !boost) {
+        const bool from_list = heavy_mode && !heavy_dry;  // this refill takes heavy pixels off the list
+        if (!exhausted && !boost && (!heavy_mode || from_list)) {
             unsigned long long need = __ballot(!active);
             // pixels_per_wave < 64: only the first lanes take pixels.  Sphere-list kernel: the others lend themselves to the
             // grouped scan; BVH kernels: the few rays have the wave's phases to themselves (shorter chain per pixel).
-            if (a.pixels_per_wave < 64) need &= (1ull << a.pixels_per_wave) - 1ull;
+            const int ppw = from_list ? a.heavy_ppw : a.pixels_per_wave;
+            if (ppw < 64) need &= (1ull << ppw) - 1ull;
             if (need) {
                 PH_BEGIN();
                 [[maybe_unused]] const bool ph_was_idle = !active;
                 const uint32_t cnt = (uint32_t)__popcll(need);
+                const uint32_t queue_len = from_list ? heavy_total : total_slots;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.cursor, cnt);
+                if (lane == 0) base = atomicAdd(from_list ? a.heavy_cursor : a.cursor, cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (base + cnt >= total_slots) exhausted = true;
+                if (base + cnt >= queue_len) {
+                    if (from_list) heavy_dry = true;
+                    else exhausted = true;
+                }
 #if RT_STAMP
                 if (exhausted && lane == 0) atomicMin(a.ray_counter + 2, (unsigned long long)wall_clock64());
 #endif
                 const uint32_t slot = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (((need >> lane) & 1ull) && slot < total_slots) {
+                if (((need >> lane) & 1ull) && slot < queue_len) {
                     // heaviest tiles first when the launcher has ranked them (see rt_render_launch); else row-major
                     const uint32_t w = slot & 63u;
-                    uint32_t tile = (RT_ORDER_ON && a.tile_order && !a.pixel_list) ? a.tile_order[slot >> 6] : slot >> 6;
+                    uint32_t tile = (RT_ORDER_ON && a.tile_order && !a.pixel_list && !from_list) ? a.tile_order[slot >> 6] : slot >> 6;
                     int pi = (int)((tile % tiles_x) * 8u + (w & 7u));
                     int lr = (int)((tile / tiles_x) * 8u + (w >> 3));
                     bool take = pi < a.width && lr < a.rows_owned;
-                    if (a.pixel_list) {  // listed pixels: compact index -> row, column
-                        const uint32_t loc = a.pixel_list[slot];
+                    if (a.pixel_list || from_list) {  // listed pixels: compact index -> row, column
+                        const uint32_t loc = from_list ? a.heavy_list[slot] : a.pixel_list[slot];
                         lr = (int)(loc / (uint32_t)a.width);
                         pi = (int)(loc % (uint32_t)a.width);
                         tile = ((uint32_t)lr >> 3) * tiles_x + ((uint32_t)pi >> 3);
@@ -2268,6 +2283,11 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
         }
         const unsigned long long live = __ballot(active);
         if (!live) {
+            if (heavy_mode && heavy_dry) {  // the list is done and so are this wave's heavy pixels: join the tile queue
+                heavy_mode = false;
+                __builtin_amdgcn_s_setprio(0);
+                continue;
+            }
             if (exhausted) break;
             continue;
         }

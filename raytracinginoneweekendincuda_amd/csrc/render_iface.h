@@ -38,6 +38,13 @@ struct RenderArgs {
     const uint32_t *pixel_list_count; // device word holding the length of pixel_list
     const uint8_t *pix_class;         // tile-queue launches: pixels whose class is non-zero belong to another launch
     int32_t wave_priority;            // s_setprio for this launch's waves (0..3)
+    // The same two classes inside ONE launch (kernels whose workgroup fills a CU: a second launch could not be resident
+    // beside it): the first `heavy_waves` waves of every workgroup serve heavy_list (heavy_ppw pixels at a time, through
+    // heavy_cursor) and join the tile queue when the list is done; the tile queue skips pix_class != 0 as above.
+    const uint32_t *heavy_list;
+    const uint32_t *heavy_count;
+    uint32_t *heavy_cursor;
+    int32_t heavy_waves, heavy_ppw, heavy_priority;
     uint32_t n_pixels;
     int32_t width, height, rows_owned;
     int32_t spp, max_depth;

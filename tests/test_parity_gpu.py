@@ -620,3 +620,24 @@ def test_library_tree_on_a_mixed_primitive_world():
         assert st_own.kernel_kind == 64 and st_ref.kernel_kind == 0
         assert st_own.rays == st_ref.rays
         assert np.array_equal(own.view(np.uint64), ref.view(np.uint64))
+
+
+def test_heavy_pixel_server_waves_give_the_same_frame(oracle):
+    """Primitive BVH worlds on the library's tree (config C3): the kernel's 768-thread workgroup fills a CU, so the pixels
+    with long ray chains are not given a launch of their own but two waves of every workgroup, which take them off the
+    list a few at a time and join the tile queue afterwards; the tile queue skips them.  Same frame, rays and streams as
+    without classes (RT_FLAG_NO_PIXEL_CLASSES), and as the oracle."""
+    w, h, spp = 512, 256, 64
+    s = rt.builtin_scene(0, 0, w, h)
+    film_a, film_b = rt.Film(w, h), rt.Film(w, h)
+    st_a = film_a.render(s, spp, variant=0)
+    st_b = film_b.render(s, spp, variant=0, flags=64)
+    a, b = film_a.download(), film_b.download()
+    assert st_a.kernel_kind == 64
+    assert st_a.rays == st_b.rays
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    want = oracle.render(0, 0, w, h, spp, rows=(120, 124))
+    assert np.array_equal(a[120:124].view(np.uint64), want[120:124].view(np.uint64))
+    film_a.render(s, 8, variant=0, flags=1)
+    film_b.render(s, 8, variant=0, flags=1 | 64)
+    assert np.array_equal(film_a.download().view(np.uint64), film_b.download().view(np.uint64))

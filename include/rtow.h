@@ -173,6 +173,9 @@ typedef struct rt_render_params {
 #define RT_FLAG_REFERENCE_TREE 128u  /* BVH worlds of primitives only are walked through the library's own tree (surface-area heuristic, near
                                       child first) -- no leaf draws random numbers there, so the closest hit is the one the reference's tree
                                       gives; this flag walks the reference's own tree in its own order instead (tests, timing) */
+#define RT_FLAG_EXACT_SCAN 256u      /* sphere-list worlds: every ray runs the reference's discriminant against every sphere (default: a cheaper
+                                      conservative filter rejects the spheres a ray's line misses and only the survivors go through the
+                                      reference's arithmetic; the image is the same bit for bit either way) */
 #define RT_FLAG_ROW_MAJOR_TILES 16u /* BVH worlds: keep the pixel queue in row-major tile order (default: a short rehearsal ranks
                                       the 8x8 tiles by rays traced and the heaviest start first; the image is the same either way) */
 

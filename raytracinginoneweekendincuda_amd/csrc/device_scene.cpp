@@ -158,6 +158,7 @@ int rt_scene_upload(rt_scene *scene, int device)
         if (rc == RT_OK) rc = upload(*dt, host, dev);
     };
     up(f.spheres, d.spheres);
+    up(f.sphere_scan, d.sphere_scan);
     up(f.sphere_aux, d.sphere_aux);
     up(f.mspheres, d.mspheres);
     up(f.ms_planes, d.ms_planes);
@@ -194,6 +195,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_world_nodes = f.n_world_nodes;
     d.scan_cost = f.scan_cost;
     d.n_spheres = (uint32_t)f.spheres.size();
+    d.scan_reach = f.scan_reach;
     d.n_mspheres = (uint32_t)f.mspheres.size();
     d.n_quads = (uint32_t)f.quads.size();
     d.n_objects = (uint32_t)f.objects.size();
@@ -400,6 +402,8 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.force_general = (p->flags & RT_FLAG_FORCE_GENERAL) ? 1 : 0;
     ra.always_walk = (p->flags & RT_FLAG_ALWAYS_WALK) ? 1 : 0;
     ra.reference_tree = (p->flags & RT_FLAG_REFERENCE_TREE) ? 1 : 0;
+    ra.exact_scan = (p->flags & RT_FLAG_EXACT_SCAN) ? 1 : 0;
+    if (const char *e = std::getenv("RTOW_EXACT_SCAN")) ra.exact_scan = std::atoi(e);
     ra.small_world = 64;  // scan budget in half sphere tests, see FlatScene::scan_cost
     if (const char *e = std::getenv("RTOW_SMALL_WORLD")) ra.small_world = std::atoi(e);  // experiments only
     const DeviceScene &ds = s.device[f.device]->scene;
@@ -424,13 +428,23 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     bool rank_tiles = bvh_kernel && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 && !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
     if (const char *e = std::getenv("RTOW_TILE_SORT")) rank_tiles = rank_tiles && std::atoi(e) != 0;  // experiments only
     const bool list_kernel = (f.last_kernel.kind & 63) >= 16 && (f.last_kernel.kind & 63) < 32, prim_bvh_kernel = (f.last_kernel.kind & 63) == 0;
-    bool split = (list_kernel || prim_bvh_kernel) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
+    // the deep general kernel (one 768-thread workgroup per CU, C5): its ray chains are the longest of all (a ray takes ~140 us
+    // in a full wave), which decides the frame whenever a GPU holds few pixels per lane -- a small frame, or one rank's share
+    const bool deep_kernel = (f.last_kernel.kind & 63) == 7 && f.last_kernel.lds_bytes > 64 * 1024;
+    // Measured and not adopted: with the fixed threshold most of C5's pixels through the mist and the glass count as heavy and
+    // two server waves per workgroup take ten times as long over them (1/8 of the frame at 200 spp: 789 -> 1900 ms).
+    bool deep_roles = false;
+    if (const char *e = std::getenv("RTOW_ROLES_DEEP")) deep_roles = deep_kernel && std::atoi(e) != 0;  // experiments only
+    bool split = (list_kernel || prim_bvh_kernel || deep_roles) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
                  f.n_pixels >= 65536u && p->pixels_per_wave <= 0 && !std::getenv("RTOW_PIXELS_PER_WAVE");
     if (const char *e = std::getenv("RTOW_PIXEL_CLASSES")) split = split && std::atoi(e) != 0;  // experiments only
     // The primitive-BVH kernel on the reference's tree (256-thread workgroups) gained nothing from a second launch (C3
     // 1672 -> 1100-1200: opt-in); the library-tree kernel, whose 768-thread workgroup fills a CU, serves both classes in
     // ONE launch, by wave (RenderArgs::heavy_list): C3 2106 -> 2713 Msamples/s.
-    bool roles_in_one_launch = prim_bvh_kernel && (f.last_kernel.kind & 64) != 0;
+    // Sphere-list worlds: both forms work; serving the heavy pixels from two waves of every workgroup lets the launch keep
+    // three workgroups per CU resident (a third wave per SIMD: +15 % in the steady state, which a frame whose end is set by
+    // its long pixels could not use) -- C2 1479 (two launches, two workgroups per CU) -> 1556 Msamples/s.
+    bool roles_in_one_launch = (prim_bvh_kernel && (f.last_kernel.kind & 64) != 0) || deep_roles || list_kernel;
     if (prim_bvh_kernel && !roles_in_one_launch && !std::getenv("RTOW_PIXEL_CLASSES")) split = false;
     if (const char *e = std::getenv("RTOW_ROLES")) roles_in_one_launch = std::atoi(e) != 0;  // experiments only
     if (rank_tiles || split) {
@@ -477,6 +491,10 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
             }
             if (roles_in_one_launch) {
                 int heavy_waves = 2;
+                if (list_kernel) {
+                    if (!std::getenv("RTOW_HEAVY_PPW")) heavy_ppw = 8;
+                    if (ra.max_blocks_per_cu <= 0) ra.max_blocks_per_cu = 3;
+                }
                 if (const char *e = std::getenv("RTOW_HEAVY_WAVES")) heavy_waves = std::atoi(e);  // experiments only
                 ra.heavy_list = f.heavy_list;
                 ra.heavy_count = f.heavy_count;

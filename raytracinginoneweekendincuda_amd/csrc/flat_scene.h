@@ -29,6 +29,8 @@ static inline constexpr uint32_t make_ref(uint32_t tag, uint32_t index) { return
 
 // Sphere (R/Sphere.h:12-20).  geom = what the discriminant test needs; aux = what shading needs.
 struct SphereGeom { double cx, cy, cz, r2; };            // r2 = radius * radius
+// The same sphere as the conservative filter of the list scan reads it (render.hip filter_four): k = |c|^2 - r^2.
+struct SphereScanRow { double cx, cy, cz, k; };
 struct SphereAux { double inv_r; uint32_t mat; uint32_t pad; };
 
 // MovingSphere (R/MovingSphere.h:19-36): centre(t) = c0 + ((t - t0) / dt) * dc
@@ -144,6 +146,8 @@ enum : uint32_t { WORLD_BVH = 0u, WORLD_LIST = 1u };
 // What the kernel receives (by value).  All pointers are device pointers.
 struct DeviceScene {
     const SphereGeom *spheres;
+    const SphereScanRow *sphere_scan;  // parallel to spheres
+    double scan_reach;                 // max over spheres of |centre| + radius (bounds the filter's rounding error)
     const SphereAux *sphere_aux;
     const MSphereGeom *mspheres;
     const SphereAux *msphere_aux;

@@ -1361,6 +1361,165 @@ DEV void rows_arrived(const SphereGeom &g0, const SphereGeom &g1, const SphereGe
     asm volatile("" ::"s"(g2.cx), "s"(g2.cy), "s"(g2.cz), "s"(g2.r2), "s"(g3.cx), "s"(g3.cy), "s"(g3.cz), "s"(g3.r2));
 }
 
+// ---- conservative filter of the list scan -------------------------------------------------------------------------
+// The reference tests a ray against a sphere with b = oc.d, c = oc.oc - r^2, disc = b*b - a*c (R/Sphere.h:28-41): 13
+// fp64 instructions with the compare, for every sphere of the list, and all but a few per ray end at `disc > 0` false.
+// Those are only *rejections*, so they need not be computed the reference's way -- any test that never rejects a sphere
+// the reference would accept leaves the image bit for bit the same, as long as the survivors then go through the
+// reference's arithmetic (drain_queue).  With u = d/|d|, od = o.u, p = o - od u (the ray's foot point) and, per sphere,
+// K = |C|^2 - r^2 (host, scene_builder.cpp):
+//     disc / a  =  ((o-C).u)^2 - (|o-C|^2 - r^2)  =  (C.u)^2 + 2 p.C - K  -  (o.o - od^2)
+// i.e. Q = fma(s, s, t) with s = C.u (3 instructions), t = 2p.C - (o.o - od^2) (3 fma), compared with the sphere's K: 8
+// instructions (the per-ray term is the addend that opens the chain and K is an operand of the compare: either as an
+// addend of its own would cost a move from the scalar row into a vector register).
+// Rounding: every term above is at most W^2 in magnitude, W = |o| + max(|C| + r) (`scan_reach`); the 8 operations, the
+// rounding of u (three divisions and a square root, so u is neither exactly unit nor exactly parallel to d), of K, p and
+// od, and the reference's own rounding of disc (divided by a) each move the comparison by at most a few u W^2,
+// u = 2^-53; their sum is below 64 u W^2.  The filter lowers the threshold by M = 2^-40 W^2 (8192 u W^2): it passes
+// whenever the reference's disc, however rounded, is positive, and a sphere of radius r is passed in vain only by rays
+// that miss it by less than M / 2r (4e-6 W^2 / r world units^2: for config C2, W = 2013, a band of 1e-5 of a small
+// sphere's radius).  A ray with a non-finite or vanishing direction passes every sphere (u = p = 0, addend +inf).
+// The reference's second shortcut -- the sphere is behind an outside origin, sphere_test -- is applied to the survivors
+// with the same margin: bu = od - s > sqrt(M) and bu^2 - disc/a > M imply b > 0 and c > 0 in the reference's arithmetic.
+struct ScanRay {
+    Vec u, p2;           // d / |d|,  2 (o - (o.u) u)
+    double nthr;         // M - (o.o - (o.u)^2)
+    double od, root_m;   // o.u,  sqrt(M)
+};
+DEV ScanRay scan_ray(const Ray &r, double a, double reach)
+{
+    ScanRay f;
+    const double oo = dot(r.o, r.o);
+    const double w = sqrt(oo) + reach;
+    const bool sane = a > 1e-280 && a < 1e280 && w < 1e140;
+    if (sane) {
+        const double inv = 1.0 / sqrt(a);
+        f.u = inv * r.d;
+        f.od = dot(r.o, f.u);
+        f.p2 = 2.0 * (r.o - f.od * f.u);
+        f.root_m = 0x1p-20 * w;
+        f.nthr = f.root_m * f.root_m - (oo - f.od * f.od);
+    } else {
+        f.u = f.p2 = mk(0.0, 0.0, 0.0);
+        f.od = 0.0;
+        f.root_m = __builtin_inf();
+        f.nthr = __builtin_inf();
+    }
+    return f;
+}
+DEV double filter_s(const ScanRay &f, double cx, double cy, double cz)
+{
+    return __builtin_fma(cz, f.u.z, __builtin_fma(cy, f.u.y, cx * f.u.x));
+}
+DEV double filter_q(const ScanRay &f, double s, double cx, double cy, double cz)  // the sphere passes when this exceeds its K
+{
+    return __builtin_fma(s, s, __builtin_fma(f.p2.z, cz, __builtin_fma(f.p2.y, cy, __builtin_fma(f.p2.x, cx, f.nthr))));
+}
+DEV bool filter_behind(const ScanRay &f, double s, double q, double k)  // only for a sphere that passed: q > k
+{
+    const double bu = f.od - s;
+    return bu > f.root_m && __builtin_fma(bu, bu, k - q) > 0.0;
+}
+
+DEV SphereScanRow load_scan_row(const SphereScanRow *table, uint32_t k)
+{
+    const RT_CONST double *p = const_doubles(table + k);
+    return SphereScanRow{p[0], p[1], p[2], p[3]};
+}
+DEV void scan_rows_arrived(const SphereScanRow &g0, const SphereScanRow &g1, const SphereScanRow &g2, const SphereScanRow &g3)
+{
+    asm volatile("" ::"s"(g0.cx), "s"(g0.cy), "s"(g0.cz), "s"(g0.k), "s"(g1.cx), "s"(g1.cy), "s"(g1.cz), "s"(g1.k));
+    asm volatile("" ::"s"(g2.cx), "s"(g2.cy), "s"(g2.cz), "s"(g2.k), "s"(g3.cx), "s"(g3.cy), "s"(g3.cz), "s"(g3.k));
+}
+
+// Four spheres through the filter: four independent chains, one branch for the four of them.
+DEV void filter_four(const SphereScanRow &g0, const SphereScanRow &g1, const SphereScanRow &g2, const SphereScanRow &g3, uint32_t k0,
+                     const ScanRay &f, uint16_t *queue, uint32_t lane, uint32_t &count)
+{
+    const SphereScanRow *g[4] = {&g0, &g1, &g2, &g3};
+    double s[4], q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        s[u] = filter_s(f, g[u]->cx, g[u]->cy, g[u]->cz);
+        q[u] = filter_q(f, s[u], g[u]->cx, g[u]->cy, g[u]->cz);
+    }
+    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    const bool p0 = q[0] > g0.k, p1 = q[1] > g1.k, p2 = q[2] > g2.k, p3 = q[3] > g3.k;
+    if (p0 | p1 | p2 | p3) {
+        const bool p[4] = {p0, p1, p2, p3};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (p[u] && !filter_behind(f, s[u], q[u], g[u]->k)) {
+                queue[count * 64u + lane] = (uint16_t)(k0 + u);
+                count++;
+            }
+        }
+    }
+}
+
+// drain_queue for survivors of the filter: the reference's whole test, `disc > 0` included.
+DEV void drain_filtered(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
+                        const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
+{
+    for (uint32_t s = 0; s < count; s++) {
+        uint32_t k = queue[s * 64u + lane];
+        SphereGeom g = spheres[k];
+        double t;
+        if (sphere_test(r.o - mk(g.cx, g.cy, g.cz), r.d, a, g.r2, tmin, closest, t)) {
+            closest = t;
+            best_k = k;
+        }
+    }
+    count = 0;
+}
+
+// Pixel-parallel scan through the filter: sphere rows are wave-uniform (scalar path), eight per trip in two register sets
+// as in scan_uniform below.
+DEV bool scan_filtered(const DeviceScene &sc, uint16_t *queue, uint32_t lane, const Ray &r, double tmin, double tmax, HitInfo &best)
+{
+    const SphereScanRow *__restrict__ rows = sc.sphere_scan;
+    const SphereGeom *__restrict__ spheres = sc.spheres;
+    const uint32_t n = sc.n_spheres;
+    const uint32_t n8 = n & ~7u;
+    const double a = dot(r.d, r.d);
+    const ScanRay f = scan_ray(r, a, sc.scan_reach);
+    double closest = tmax;
+    uint32_t best_k = kNone, count = 0;
+    SphereScanRow a0{}, a1{}, a2{}, a3{};
+    if (n8) {
+        a0 = load_scan_row(rows, 0); a1 = load_scan_row(rows, 1);
+        a2 = load_scan_row(rows, 2); a3 = load_scan_row(rows, 3);
+    }
+    for (uint32_t k0 = 0; k0 < n8; k0 += 8) {
+        scan_rows_arrived(a0, a1, a2, a3);
+        const SphereScanRow b0 = load_scan_row(rows, k0 + 4), b1 = load_scan_row(rows, k0 + 5);
+        const SphereScanRow b2 = load_scan_row(rows, k0 + 6), b3 = load_scan_row(rows, k0 + 7);
+        filter_four(a0, a1, a2, a3, k0, f, queue, lane, count);
+        const uint32_t kn = (k0 + 8 < n8) ? k0 + 8 : k0;  // last trip re-reads its own rows (stays in bounds)
+        scan_rows_arrived(b0, b1, b2, b3);
+        a0 = load_scan_row(rows, kn); a1 = load_scan_row(rows, kn + 1);
+        a2 = load_scan_row(rows, kn + 2); a3 = load_scan_row(rows, kn + 3);
+        filter_four(b0, b1, b2, b3, k0 + 4, f, queue, lane, count);
+        if (__any(count > (uint32_t)(kQueueCap - 8))) drain_filtered(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    }
+    for (uint32_t k = n8; k < n; k++) {
+        const SphereScanRow g = load_scan_row(rows, k);
+        const double s = filter_s(f, g.cx, g.cy, g.cz);
+        const double q = filter_q(f, s, g.cx, g.cy, g.cz);
+        if (q > g.k && !filter_behind(f, s, q, g.k)) {
+            queue[count * 64u + lane] = (uint16_t)k;
+            count++;
+        }
+        if (__any(count >= (uint32_t)kQueueCap)) drain_filtered(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    }
+    drain_filtered(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    if (best_k == kNone) return false;
+    best.t = closest;
+    best.ref = make_ref(REF_SPHERE, best_k);
+    best.obj = kNone;
+    return true;
+}
+
 // Pixel-parallel scan: every live lane traces its own ray; sphere rows are wave-uniform (scalar path).
 DEV bool scan_uniform(const DeviceScene &sc, uint16_t *queue, uint32_t lane, const Ray &r, double tmin, double tmax, HitInfo &best)
 {
@@ -1414,7 +1573,9 @@ struct SphereView {
     // The LDS planes are addressed as byte offsets off the __shared__ symbol (plane(p, k)), never through pointers: a
     // pointer that may be LDS or global makes the compiler emit flat loads (19 of them in this kernel before), which are
     // slower than ds_read and tie up both wait counters.
-    uint32_t planes_off;  // byte offset of plane 0 (cx); planes of n_padded doubles: cx, cy, cz, r2
+    uint32_t planes_off;  // byte offset of plane 0 (cx); planes of n_padded doubles: cx, cy, cz, r2, K (filter_four's |c|^2 - r^2)
+    double reach;         // DeviceScene::scan_reach
+    bool exact;           // RT_FLAG_EXACT_SCAN: the reference's discriminant for every sphere, no filter
     const SphereGeom *global;
     uint32_t n, n_padded;
     bool in_lds;
@@ -1465,7 +1626,33 @@ DEV void scan_cooperative(const SphereView &sv, uint32_t lane, unsigned long lon
         const double a = dot(r.d, r.d);
         double bt = tmax;
         uint32_t bk = kNone;
-        if (sv.in_lds) {
+        if (sv.in_lds && !sv.exact) {
+            const ScanRay f = scan_ray(r, a, sv.reach);
+            for (uint32_t base = 0; base < sv.n_padded; base += 256u) {
+                double q[4];
+                bool pass[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t k = base + 64u * u + lane;
+                    k = k < sv.n_padded ? k : sv.n_padded - 1u;
+                    const double cx = sv.plane(0, k), cy = sv.plane(1, k), cz = sv.plane(2, k);
+                    const double fs = filter_s(f, cx, cy, cz);
+                    q[u] = filter_q(f, fs, cx, cy, cz);
+                    pass[u] = q[u] > sv.plane(4, k);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = base + 64u * u + lane;
+                    if (k < sv.n && pass[u]) {  // the reference's whole test for the survivors
+                        double t;
+                        if (sphere_test(r.o - mk(sv.plane(0, k), sv.plane(1, k), sv.plane(2, k)), r.d, a, sv.plane(3, k), tmin, bt, t)) {
+                            bt = t;
+                            bk = k;
+                        }
+                    }
+                }
+            }
+        } else if (sv.in_lds) {
             for (uint32_t base = 0; base < sv.n_padded; base += 256u) {
                 double b[4], c[4], disc[4];
 #pragma unroll
@@ -1562,6 +1749,31 @@ DEV void scan_grouped(const SphereView &sv, uint32_t lane, unsigned long long to
     const double a = dot(r.d, r.d);
     double bt = tmax;
     uint32_t bk = kNone;
+    if (!sv.exact) {
+        const ScanRay f = scan_ray(r, a, sv.reach);
+        for (uint32_t base = 0; base < sv.n_padded; base += 4u * g) {
+            bool pass[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t k = base + g * u + s;
+                k = k < sv.n_padded ? k : sv.n_padded - 1u;  // keeps the address inside the planes
+                const double cx = sv.plane(0, k), cy = sv.plane(1, k), cz = sv.plane(2, k);
+                const double fs = filter_s(f, cx, cy, cz);
+                pass[u] = filter_q(f, fs, cx, cy, cz) > sv.plane(4, k);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = base + g * u + s;
+                if (k < sv.n && pass[u]) {  // the reference's whole test for the survivors
+                    double t;
+                    if (sphere_test(r.o - mk(sv.plane(0, k), sv.plane(1, k), sv.plane(2, k)), r.d, a, sv.plane(3, k), tmin, bt, t)) {
+                        bt = t;
+                        bk = k;
+                    }
+                }
+            }
+        }
+    } else
     for (uint32_t base = 0; base < sv.n_padded; base += 4u * g) {
         double b[4], c[4], disc[4];
 #pragma unroll
@@ -2132,6 +2344,8 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
         sv.n = sc.n_spheres;
         sv.n_padded = (sc.n_spheres + 63u) & ~63u;
         sv.in_lds = a.lds_spheres != 0;
+        sv.reach = sc.scan_reach;
+        sv.exact = a.exact_scan != 0;
         if (sv.in_lds) {
             sv.planes_off = ((uint32_t)T::BLOCK / 64u) * kQueueCap * 64u * (uint32_t)sizeof(uint16_t);
             double *planes = reinterpret_cast<double *>(lds_raw + sv.planes_off);
@@ -2139,6 +2353,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
                 SphereGeom g = sc.spheres[k < sv.n ? k : 0];
                 planes[k] = g.cx; planes[np + k] = g.cy; planes[2 * np + k] = g.cz; planes[3 * np + k] = g.r2;
+                planes[4 * np + k] = sc.sphere_scan[k < sv.n ? k : 0].k;
             }
             __syncthreads();
         }
@@ -2303,7 +2518,8 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             if (boost) todo = overdue;
             if (!boost && a.pixels_per_wave >= 64 && __popcll(live) >= a.coop_threshold) {
                 PH_BEGIN();
-                if (active) hit = scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h);
+                if (active) hit = a.exact_scan ? scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h)
+                                               : scan_filtered(sc, queue, lane, ray, 0.001, DBL_MAX, h);
                 PH_END(0, active);
             } else {
                 PH_BEGIN();
@@ -2737,7 +2953,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
         }
     } else if (T::WORLD == 2) {
         lds = (T::BLOCK / 64) * kQueueCap * 64 * sizeof(uint16_t);
-        size_t planes = (size_t)((sc.n_spheres + 63u) & ~63u) * 4 * sizeof(double);
+        size_t planes = (size_t)((sc.n_spheres + 63u) & ~63u) * 5 * sizeof(double);
         a.lds_spheres = 0;
         if (planes <= 48 * 1024) {
             lds += planes;

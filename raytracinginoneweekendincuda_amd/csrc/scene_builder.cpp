@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -952,6 +953,25 @@ int flatten_scene(SceneImpl &s)
         f.scan_cost = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
     }
     build_fast_tree(f);
+    {
+        // Rows of the list scan's conservative filter (render.hip filter_four): centre and |c|^2 - r^2, and the
+        // scene's reach max(|c| + r) that bounds the filter's rounding error.  A non-finite row becomes (0, 0, 0, -inf):
+        // such a sphere passes the filter for every ray and the exact test decides.
+        f.sphere_scan.clear();
+        f.scan_reach = 0.0;
+        for (const SphereGeom &g : f.spheres) {
+            const long double cc = (long double)g.cx * g.cx + (long double)g.cy * g.cy + (long double)g.cz * g.cz;
+            double k = (double)(cc - (long double)g.r2);
+            double reach = std::sqrt((double)cc) + std::sqrt(std::fabs(g.r2));
+            if (!std::isfinite(k) || !std::isfinite(reach)) {
+                f.sphere_scan.push_back(SphereScanRow{0.0, 0.0, 0.0, -std::numeric_limits<double>::infinity()});
+                continue;
+            }
+            f.sphere_scan.push_back(SphereScanRow{g.cx, g.cy, g.cz, k});
+            f.scan_reach = std::max(f.scan_reach, reach);
+        }
+        f.scan_reach *= 1.0 + 0x1p-40;  // the two square roots above were rounded
+    }
     {
         bool unit_time = !f.mspheres.empty();
         for (const MSphereGeom &m : f.mspheres) unit_time &= (m.t0 == 0.0 && m.dt == 1.0);

@@ -573,6 +573,37 @@ def test_heavy_and_light_pixels_in_two_launches_give_the_same_frame(oracle):
     assert np.array_equal(film_a.download().view(np.uint64), film_b.download().view(np.uint64))
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("scene_id,shape", [(11, (512, 256, 32)), (10, (160, 96, 24)), (1, (96, 64, 16)), (11, (64, 40, 16))])
+def test_filtered_list_scan_gives_the_exact_scans_frame(oracle, scene_id, shape, variant):
+    """Sphere-list worlds: every ray examines every sphere, but through an 8-instruction conservative filter
+    (render.hip filter_four) instead of the reference's 13-instruction discriminant; only the spheres the filter cannot
+    rule out go through the reference's arithmetic.  A filter that never rejects what the reference accepts changes
+    nothing: the frame, the ray count and the RNG streams are those of the exact scan (RT_FLAG_EXACT_SCAN = 256) bit for
+    bit, in both builds, for the pixel-parallel scan, the heavy-pixel groups and the frame-tail cooperative scan; the
+    strict build's rows equal the oracle's."""
+    w, h, spp = shape
+    s = rt.builtin_scene(scene_id, 1, w, h)
+    film_a, film_b = rt.Film(w, h), rt.Film(w, h)
+    st_a = film_a.render(s, spp, variant=variant)
+    st_b = film_b.render(s, spp, variant=variant, flags=rt.FLAG_EXACT_SCAN)
+    assert st_a.kernel_kind == 16
+    assert st_a.rays == st_b.rays
+    a, b = film_a.download(), film_b.download()
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    if variant == 0:
+        rows = (h // 2, h // 2 + 2)
+        want = oracle.render(scene_id, 1, w, h, spp, rows=rows)
+        assert np.array_equal(a[rows[0]:rows[1]].view(np.uint64), want[rows[0]:rows[1]].view(np.uint64))
+    film_a.render(s, 4, variant=variant, flags=1)
+    film_b.render(s, 4, variant=variant, flags=1 | rt.FLAG_EXACT_SCAN)
+    assert np.array_equal(film_a.download().view(np.uint64), film_b.download().view(np.uint64))
+    # a few pixels per wave: every scan of the frame is a grouped scan
+    g1, st1 = s.render(w, h, 4, variant=variant, pixels_per_wave=8)
+    g2, st2 = s.render(w, h, 4, variant=variant, pixels_per_wave=8, flags=rt.FLAG_EXACT_SCAN)
+    assert st1.rays == st2.rays and np.array_equal(g1.view(np.uint64), g2.view(np.uint64))
+
+
 @pytest.mark.parametrize("scene_id", [0, 11, 3])
 @pytest.mark.parametrize("variant", [0])
 def test_library_tree_gives_the_reference_trees_frame(oracle, scene_id, variant):

@@ -52,6 +52,8 @@ BYTES = {"box_tests": 56, "sphere_tests": 36, "msphere_tests": 76, "quad_tests":
 SLOTS = {"box_tests": 25, "sphere_tests": 13, "msphere_tests": 16, "quad_tests": 19, "xform_entries": 6,
          "medium_draws": 45, "scatters": 40, "noise_calls": 140, "rays": 58}
 SLOTS_LIST_WORLD_RAY = 28     # list worlds need no 1/d per ray
+SLOTS_FILTERED_SPHERE = 8     # what the sphere-list kernel executes per sphere: the conservative filter (render.hip filter_four)
+SLOTS_FILTER_SETUP = 60       # and per ray: 1/|d| (sqrt + divide), foot point, thresholds
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TF fp32 vector rate: one wave64 fp64 instruction per 4 cycles per SIMD
 PEAK_SLOTS_PER_S = 1024 * 2.4e9 * 64 / 4   # lane-instructions/s: 1024 SIMDs, 2.4 GHz, 16 lanes per cycle
@@ -131,9 +133,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", default="auto", choices=["auto", "strict", "fast"],
-                    help="auto = the fast build (FMA contraction) where its frame stays within the parity tolerance of the oracle "
-                         "at the benchmark's own spp (C2, C3, C4: >= 99.98 %% of pixels within 1e-5), the strict build for C5, where "
-                         "5000 samples per pixel through media give a contracted comparison a chance to flip in every pixel")
+                    help="auto = the strict build (the reference's arithmetic, bit-identical frames) for C2, where it is within a few "
+                         "per cent of the fast one, and for C5, where 5000 samples per pixel through media give a contracted comparison "
+                         "a chance to flip in every pixel; the fast build (FMA contraction) for C3 and C4, whose frames stay within the "
+                         "parity tolerance at the benchmark's own spp (>= 99.98 %% of pixels within 1e-5)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N GPUs: weak = N x the rows of the base frame (default), strong = the base frame striped over the ranks")
@@ -172,7 +175,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     if args.variant == "auto":
-        args.variant = "strict" if args.workload == "c5" else "fast"
+        args.variant = "strict" if args.workload in ("c2", "c5") else "fast"
     scene_id, world_kind, W, H0, spp, desc = wl
     if args.spp:
         spp = args.spp
@@ -343,6 +346,7 @@ def main():
                 "traffic_source": traffic_src if traffic is not None else "not measured in this run; no committed PMC profile of this configuration",
                 "slots_per_ray": slots_per_ray, "slots_per_s": slots_per_s, "peak_slots_per_s": PEAK_SLOTS_PER_S,
                 "tests_per_ray": {k: stats[k] / n_rays for k in slots if k != "rays"},
+                "executed": None,
                 "note": "achieved = algorithmic fp64 VALU instruction slots per ray (oracle-counted element tests x the slot table "
                         "in bench.py / DESIGN.md) x rays of the timed launch / HIP-event kernel time, expressed at 2 flop per slot "
                         "against the 78.6 TFLOP/s vector-fp64 peak (one wave64 instruction per 4 cycles per SIMD at 2.4 GHz)",
@@ -352,6 +356,16 @@ def main():
                     "note": "SURVEY 8d definition (element sizes x oracle-counted tests per ray / kernel time); the tables are "
                             "chip-resident (scalar cache / LDS / L2), so this is not a bound and may exceed 1"},
             }
+            if args.workload == "c2" and not (args.flags & 256):
+                ex = dict(slots)
+                ex["sphere_tests"] = SLOTS_FILTERED_SPHERE
+                ex["rays"] = slots["rays"] + SLOTS_FILTER_SETUP
+                ex_per_ray = sum(ex[k] * stats[k] for k in ex) / n_rays
+                out["roofline"]["executed"] = {
+                    "slots_per_ray": ex_per_ray, "frac": ex_per_ray * float(rays) / kernel_avg / PEAK_SLOTS_PER_S,
+                    "note": "the same ratio with the slots the kernel issues instead of the reference's arithmetic: every sphere of "
+                            "the list goes through an 8-instruction conservative filter (13 for the reference's discriminant and "
+                            "compare), the few survivors per ray through the reference's test; frac above counts the reference's 13"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

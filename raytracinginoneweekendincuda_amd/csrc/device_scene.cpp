@@ -404,6 +404,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.reference_tree = (p->flags & RT_FLAG_REFERENCE_TREE) ? 1 : 0;
     ra.exact_scan = (p->flags & RT_FLAG_EXACT_SCAN) ? 1 : 0;
     if (const char *e = std::getenv("RTOW_EXACT_SCAN")) ra.exact_scan = std::atoi(e);
+    if (const char *e = std::getenv("RTOW_HEAVY_SCAN")) ra.heavy_scan = std::atoi(e);
     ra.small_world = 64;  // scan budget in half sphere tests, see FlatScene::scan_cost
     if (const char *e = std::getenv("RTOW_SMALL_WORLD")) ra.small_world = std::atoi(e);  // experiments only
     const DeviceScene &ds = s.device[f.device]->scene;
@@ -493,6 +494,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
                 int heavy_waves = 2;
                 if (list_kernel) {
                     if (!std::getenv("RTOW_HEAVY_PPW")) heavy_ppw = 8;
+                    if (!std::getenv("RTOW_HEAVY_PRIO")) heavy_prio = 3;  // the serving waves' rays are the frame's critical path
                     if (ra.max_blocks_per_cu <= 0) ra.max_blocks_per_cu = 3;
                 }
                 if (const char *e = std::getenv("RTOW_HEAVY_WAVES")) heavy_waves = std::atoi(e);  // experiments only
@@ -555,6 +557,21 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         HIP_TRY(hipEventElapsedTime(&ms_seed, f.ev[0], f.ev[1]));
         HIP_TRY(hipEventElapsedTime(&ms_render, f.ev[1], f.ev[2]));
         const unsigned long long rays = f.host_counters[0];
+        if (std::getenv("RTOW_PRINT_HEAVY") && f.heavy_count && f.pix_cost) {  // diagnostics: the rehearsal's cost classes
+            uint32_t n_heavy = 0;
+            std::vector<uint32_t> cost(f.n_pixels);
+            HIP_TRY(hipMemcpy(&n_heavy, f.heavy_count, sizeof n_heavy, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(cost.data(), f.pix_cost, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            unsigned long long hist[16] = {};
+            uint32_t top = 0;
+            for (uint32_t c : cost) {
+                hist[c / 16 > 15 ? 15 : c / 16]++;
+                top = c > top ? c : top;
+            }
+            std::fprintf(stderr, "heavy pixels %u of %u; probe rays per pixel: max %u; histogram by 16:", n_heavy, f.n_pixels, top);
+            for (int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", hist[k]);
+            std::fprintf(stderr, "\n");
+        }
         if (std::getenv("RTOW_PRINT_STAMPS")) {  // diagnostic builds (-DRT_STAMP=1): 100 MHz wall-clock ticks
             const unsigned long long *st = f.host_counters;
             std::fprintf(stderr, "stamps: start %llu  queue exhausted +%.3f ms  first wave out +%.3f ms  last wave out +%.3f ms\n",

@@ -1457,13 +1457,21 @@ DEV void filter_four(const SphereScanRow &g0, const SphereScanRow &g1, const Sph
     }
 }
 
-// drain_queue for survivors of the filter: the reference's whole test, `disc > 0` included.
-DEV void drain_filtered(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
-                        const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
+// drain_queue for survivors of the filter: the reference's whole test, `disc > 0` included.  ROWS_IN_LDS: the rows come
+// from the LDS planes of the cooperative scan (a queue entry costs one LDS round trip instead of one to L2).
+template <bool ROWS_IN_LDS>
+DEV void drain_filtered(const SphereGeom *__restrict__ spheres, uint32_t planes_off, uint32_t n_padded, const uint16_t *queue, uint32_t lane,
+                        uint32_t &count, const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
 {
     for (uint32_t s = 0; s < count; s++) {
         uint32_t k = queue[s * 64u + lane];
-        SphereGeom g = spheres[k];
+        SphereGeom g;
+        if constexpr (ROWS_IN_LDS) {
+            const RT_LDS double *pl = (const RT_LDS double *)(lds_raw + planes_off);
+            g = SphereGeom{pl[k], pl[n_padded + k], pl[2u * n_padded + k], pl[3u * n_padded + k]};
+        } else {
+            g = spheres[k];
+        }
         double t;
         if (sphere_test(r.o - mk(g.cx, g.cy, g.cz), r.d, a, g.r2, tmin, closest, t)) {
             closest = t;
@@ -1475,7 +1483,9 @@ DEV void drain_filtered(const SphereGeom *__restrict__ spheres, const uint16_t *
 
 // Pixel-parallel scan through the filter: sphere rows are wave-uniform (scalar path), eight per trip in two register sets
 // as in scan_uniform below.
-DEV bool scan_filtered(const DeviceScene &sc, uint16_t *queue, uint32_t lane, const Ray &r, double tmin, double tmax, HitInfo &best)
+template <bool ROWS_IN_LDS>
+DEV bool scan_filtered(const DeviceScene &sc, uint32_t planes_off, uint32_t n_padded, uint16_t *queue, uint32_t lane, const Ray &r, double tmin,
+                       double tmax, HitInfo &best)
 {
     const SphereScanRow *__restrict__ rows = sc.sphere_scan;
     const SphereGeom *__restrict__ spheres = sc.spheres;
@@ -1500,7 +1510,7 @@ DEV bool scan_filtered(const DeviceScene &sc, uint16_t *queue, uint32_t lane, co
         a0 = load_scan_row(rows, kn); a1 = load_scan_row(rows, kn + 1);
         a2 = load_scan_row(rows, kn + 2); a3 = load_scan_row(rows, kn + 3);
         filter_four(b0, b1, b2, b3, k0 + 4, f, queue, lane, count);
-        if (__any(count > (uint32_t)(kQueueCap - 8))) drain_filtered(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+        if (__any(count > (uint32_t)(kQueueCap - 8))) drain_filtered<ROWS_IN_LDS>(spheres, planes_off, n_padded, queue, lane, count, r, a, tmin, closest, best_k);
     }
     for (uint32_t k = n8; k < n; k++) {
         const SphereScanRow g = load_scan_row(rows, k);
@@ -1510,9 +1520,9 @@ DEV bool scan_filtered(const DeviceScene &sc, uint16_t *queue, uint32_t lane, co
             queue[count * 64u + lane] = (uint16_t)k;
             count++;
         }
-        if (__any(count >= (uint32_t)kQueueCap)) drain_filtered(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+        if (__any(count >= (uint32_t)kQueueCap)) drain_filtered<ROWS_IN_LDS>(spheres, planes_off, n_padded, queue, lane, count, r, a, tmin, closest, best_k);
     }
-    drain_filtered(spheres, queue, lane, count, r, a, tmin, closest, best_k);
+    drain_filtered<ROWS_IN_LDS>(spheres, planes_off, n_padded, queue, lane, count, r, a, tmin, closest, best_k);
     if (best_k == kNone) return false;
     best.t = closest;
     best.ref = make_ref(REF_SPHERE, best_k);
@@ -2519,7 +2529,8 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             if (!boost && a.pixels_per_wave >= 64 && __popcll(live) >= a.coop_threshold) {
                 PH_BEGIN();
                 if (active) hit = a.exact_scan ? scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h)
-                                               : scan_filtered(sc, queue, lane, ray, 0.001, DBL_MAX, h);
+                                 : sv.in_lds ? scan_filtered<true>(sc, sv.planes_off, sv.n_padded, queue, lane, ray, 0.001, DBL_MAX, h)
+                                             : scan_filtered<false>(sc, 0u, 0u, queue, lane, ray, 0.001, DBL_MAX, h);
                 PH_END(0, active);
             } else {
                 PH_BEGIN();
@@ -2531,7 +2542,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
         bool thin = false;
         if constexpr (T::WORLD == 0 && !T::COMPOSITE) {
             // Frame tail of a sphere world: the queue is dry and few lanes are left -- scan instead of walking (scan_grouped_ms).
-            thin = exhausted && sc.ms_planes != nullptr && __popcll(live) < a.coop_threshold;
+            thin = sc.ms_planes != nullptr && ((exhausted && __popcll(live) < a.coop_threshold) || (heavy_mode && a.heavy_scan));
             if (thin) {
                 PH_BEGIN();
                 scan_grouped_ms(sc, lane, live, ray, 0.001, DBL_MAX, h, hit);
@@ -2869,7 +2880,10 @@ using TBvhInstances = Traits<0, true, false, RT_WAVES_INSTANCES, false>;  // ins
 // SIMD runs at half the speed of two -- so three waves with a hundred-odd registers spilled to scratch still win
 // (Cornell smoke +5 %, C5 +4.5 %).  A shallow world with expensive shading (Perlin, image texture) loses a third that
 // way, so the general kernel exists in both shapes and the launcher picks by the depth of the world's tree.
-using TBvhMedia = Traits<0, true, false, 3, true>;                      // + ConstantMedium (Cornell smoke)
+#ifndef RT_WAVES_MEDIA
+#define RT_WAVES_MEDIA 3
+#endif
+using TBvhMedia = Traits<0, true, false, RT_WAVES_MEDIA, true>;                      // + ConstantMedium (Cornell smoke)
 #ifndef RT_WAVES_DEEP
 #define RT_WAVES_DEEP 3
 #endif

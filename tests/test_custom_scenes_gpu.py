@@ -231,3 +231,43 @@ def bvh_object_among_the_leaves_of_a_bvh_world(s, Rng):
 @pytest.mark.parametrize("name", sorted(NESTINGS))
 def test_general_nesting_matches_the_oracle(name):
     check(NESTINGS[name], spp=6, min_exact=0.97)
+
+
+# ---- sphere-list filter under cancellation ----
+def _far_sphere_list(offset, n=40, touching=True):
+    def build(s, Rng):
+        ox, oy, oz = offset
+        rnd = np.random.default_rng(5)
+        items = []
+        # a wall of touching spheres (silhouettes everywhere: rays that graze), some glass, a huge ground sphere
+        for k in range(n):
+            cx, cy = (k % 8) * 0.5 - 1.75, (k // 8) * 0.5 - 1.0
+            r = 0.25 if touching else 0.2
+            mat = s.Dielectric(1.5) if k % 5 == 0 else (s.Metal(tuple(rnd.uniform(0.4, 0.9, 3)), 0.0) if k % 3 == 0
+                                                         else s.Lambertian(tuple(rnd.uniform(0.1, 0.9, 3))))
+            items.append(s.Sphere((ox + cx, oy + cy, oz - 4.0), r, mat))
+        items.append(s.Sphere((ox, oy - 1000.5 - 1.0, oz - 4.0), 1000.0, s.Lambertian((0.5, 0.5, 0.5))))
+        s.SetWorld(s.HittableList(items))
+        s.Camera((ox, oy, oz), (ox, oy, oz - 4.0), (0, 1, 0), 50, 96 / 64, 0.0, 10.0)
+        s.Commit()
+    return build
+
+
+@pytest.mark.parametrize("offset", [(0.0, 0.0, 0.0), (3000.0, -2000.0, 5000.0), (1.0e6, 2.0e6, -3.0e6)])
+def test_sphere_list_filter_far_from_the_origin(offset):
+    """The list scan's conservative filter expands (o - C)^2 around the world origin, so a scene far away from it is where
+    cancellation would bite: its margin grows with (|o| + |C| + r)^2 and the filter passes more spheres, never fewer.
+    Strict build = oracle bit for bit (the oracle runs the reference's discriminant on every sphere), ray counts equal, and
+    the exact scan (RT_FLAG_EXACT_SCAN) gives the same frame in both builds."""
+    import raytracinginoneweekendincuda_amd as rt
+    w, h, spp = 96, 64, 8
+    prod, orc = build_both(_far_sphere_list(offset))
+    want, stats = orc.render(w, h, spp, want_stats=True)
+    for variant in (0, 1):
+        got, st = prod.render(w, h, spp, variant=variant)
+        ref, st_ref = prod.render(w, h, spp, variant=variant, flags=rt.FLAG_EXACT_SCAN)
+        assert st.kernel_kind == 16
+        assert st.rays == st_ref.rays and np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+        if variant == 0:
+            assert st.rays == stats["rays"]
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64))

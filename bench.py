@@ -126,6 +126,27 @@ def measured_traffic(workload, spp, variant):
     return None, None
 
 
+def measured_issue(workload, spp, variant):
+    """What the SIMDs did during a committed PMC pass of this very configuration: the share of SIMD cycles in which a VALU
+    instruction issued (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel time x 2.4 GHz) and the share of live lanes in
+    those instructions (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64).  None without such a profile."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        ms = d.get("ms_render_kernels_GRBM_GUI_ACTIVE")
+        if d.get("spp") == spp and d.get("variant", "fast") == variant and ms and d.get("SQ_INSTS_VALU"):
+            return {"valu_issue_frac": d["SQ_INSTS_VALU"] * 4.0 / (1024 * ms * 1e-3 * 2.4e9),
+                    "lane_utilisation": d.get("lane_utilisation"), "valu_instructions_per_frame": d["SQ_INSTS_VALU"],
+                    "source": os.path.relpath(path, ROOT),
+                    "note": "committed rocprofv3 --pmc pass, not this run: fraction of SIMD cycles with a VALU instruction issuing, "
+                            "and live lanes per VALU instruction; their product is the share of the chip's lane-cycles doing "
+                            "arithmetic of any kind (fp64, integer RNG, address and control work alike)"}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,6 +368,7 @@ def main():
                 "slots_per_ray": slots_per_ray, "slots_per_s": slots_per_s, "peak_slots_per_s": PEAK_SLOTS_PER_S,
                 "tests_per_ray": {k: stats[k] / n_rays for k in slots if k != "rays"},
                 "executed": None,
+                "issue": measured_issue(args.workload, spp, args.variant),
                 "note": "achieved = algorithmic fp64 VALU instruction slots per ray (oracle-counted element tests x the slot table "
                         "in bench.py / DESIGN.md) x rays of the timed launch / HIP-event kernel time, expressed at 2 flop per slot "
                         "against the 78.6 TFLOP/s vector-fp64 peak (one wave64 instruction per 4 cycles per SIMD at 2.4 GHz)",

@@ -1255,11 +1255,8 @@ DEV bool world_hit_list(const DeviceScene &sc, const Ray &r, double tmin, double
     double closest = tmax;
     bool any = false;
     const uint32_t n = sc.n_world_items;
-    const RT_CONST uint32_t *items = (const RT_CONST uint32_t *)(uintptr_t)sc.world_items;
-    uint32_t next = n ? (uint32_t)__builtin_amdgcn_readfirstlane((int)items[0]) : 0u;
     for (uint32_t k = 0; k < n; k++) {
-        const uint32_t ref = next;
-        next = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[k + 1 < n ? k + 1 : k]);  // in flight while leaf k is tested
+        const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)((const RT_CONST uint32_t *)(uintptr_t)sc.world_items)[k]);
         if (leaf_test<T>(sc, ref, r, a, tmin, closest, best, rng PH_PASS)) {
             any = true;
             closest = best.t;
@@ -2904,9 +2901,9 @@ using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP, true, true, false, 
 // are only ever launched for scenes that nest objects beyond what ObjectRec expresses (none of the ten built-in scenes).
 using TBvhNested = Traits<0, true, true, 2, true, false, true>;
 using TListNested = Traits<1, true, true, 2, true, false, true>;
-using TListPrims = Traits<1, false, false, 3>;
+using TListPrims = Traits<1, false, false, 4>;  // 127-129 VGPRs without the bound: the strict build would drop to three waves for one register
 #ifndef RT_WAVES_LIST_INSTANCES
-#define RT_WAVES_LIST_INSTANCES 3
+#define RT_WAVES_LIST_INSTANCES 4  // 128 VGPRs and 52 B of scratch for a fourth wave per SIMD: C4 +2.4 % (139 VGPRs, none, three waves before)
 #endif
 using TListInstances = Traits<1, true, false, RT_WAVES_LIST_INSTANCES, false>;
 

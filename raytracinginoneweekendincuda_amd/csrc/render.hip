@@ -2288,6 +2288,21 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a)
 template <int STRICT, class T>
 __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceScene sc, RenderArgs a)
 {
+    // What the launcher never stages for this instantiation is said here at compile time (launch_one places tables for
+    // BVH worlds only, the sphere / material rows of primitive worlds only for the library-tree kernel, the big tables of
+    // composite worlds only for the 768-thread workgroup): the LDS side of those row accessors folds away, and a
+    // wave-uniform row of a list kernel feeds the vector instructions straight from the scalar registers it was loaded
+    // into instead of being copied into vector registers to meet the other path (C4 2268 -> 2472 Msamples/s).
+    if constexpr (T::WORLD != 0 || (!T::COMPOSITE && !T::FAST)) {
+        sc.lds_quad_aa = sc.lds_boxes = sc.lds_objects = sc.lds_xforms = sc.lds_media = sc.lds_materials = sc.lds_perlin = kNone;
+        sc.lds_spheres_tab = sc.lds_group_boxes = sc.lds_mspheres = sc.lds_msphere_aux = sc.lds_sphere_aux = kNone;
+    } else if constexpr (T::FAST) {
+        sc.lds_quad_aa = sc.lds_boxes = sc.lds_objects = sc.lds_xforms = sc.lds_media = sc.lds_perlin = sc.lds_group_boxes = kNone;
+    } else {
+        sc.lds_mspheres = sc.lds_msphere_aux = sc.lds_sphere_aux = kNone;
+        if constexpr (T::BLOCK < 768) sc.lds_spheres_tab = kNone;
+        if constexpr (!T::RICH) sc.lds_perlin = kNone;
+    }
     // ---- chip-resident working set ----
     NodeView nv{};
     uint16_t *queue = nullptr;

@@ -2298,10 +2298,23 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
         sc.lds_spheres_tab = sc.lds_group_boxes = sc.lds_mspheres = sc.lds_msphere_aux = sc.lds_sphere_aux = kNone;
     } else if constexpr (T::FAST) {
         sc.lds_quad_aa = sc.lds_boxes = sc.lds_objects = sc.lds_xforms = sc.lds_media = sc.lds_perlin = sc.lds_group_boxes = kNone;
+#ifndef RT_NO_ASSUME
+        if constexpr (T::BLOCK >= 768) {  // launched only with all of its rows staged (launch_one)
+            __builtin_assume(sc.lds_mspheres != kNone && sc.lds_msphere_aux != kNone && sc.lds_spheres_tab != kNone);
+            __builtin_assume(sc.lds_sphere_aux != kNone && sc.lds_materials != kNone);
+        }
+#endif
     } else {
         sc.lds_mspheres = sc.lds_msphere_aux = sc.lds_sphere_aux = kNone;
         if constexpr (T::BLOCK < 768) sc.lds_spheres_tab = kNone;
         if constexpr (!T::RICH) sc.lds_perlin = kNone;
+#ifndef RT_NO_ASSUME
+        if constexpr (T::BATCH && T::BLOCK >= 768) {  // the deep kernel is launched only with all of these staged (launch_one)
+            __builtin_assume(sc.lds_boxes != kNone && sc.lds_objects != kNone && sc.lds_xforms != kNone);
+            __builtin_assume(sc.lds_media != kNone && sc.lds_materials != kNone && sc.lds_perlin != kNone);
+            __builtin_assume(sc.lds_spheres_tab != kNone && sc.lds_group_boxes != kNone);
+        }
+#endif
     }
     // ---- chip-resident working set ----
     NodeView nv{};
@@ -2309,7 +2322,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     if constexpr (T::WORLD == 0) {
         // BVH nodes in LDS, one 72-byte row each (see lds_node_f64 for the layout and why 72)
         nv.global = sc.nodes;
-        nv.in_lds = a.lds_nodes != 0;
+        nv.in_lds = (T::BATCH && T::BLOCK >= 768) ? true : a.lds_nodes != 0;  // the deep kernel: always (launch_one)
         if constexpr (T::FAST) {
             {  // the library's own tree: rows copied as they are (always staged: see walk_node_fast)
                 const uint32_t words = sc.n_fast_nodes * (kFastNodeBytes / 4u);
@@ -2926,6 +2939,7 @@ template <class T>
 hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream, KernelInfo *info)
 {
     DeviceScene sc = sc_in;
+    [[maybe_unused]] const RenderArgs a_in = a;
     auto kernel = render_kernel<RT_STRICT, T>;
     uint32_t tiles = (((uint32_t)a.width + 7u) >> 3) * (((uint32_t)a.rows_owned + 7u) >> 3);
     size_t lds = 0;
@@ -2953,6 +2967,16 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             place(sc.lds_sphere_aux, (size_t)sc.n_spheres * sizeof(SphereAux));
             place(sc.lds_materials, (size_t)sc.n_materials * sizeof(MaterialRec));
             lds = off;
+        }
+        if constexpr (T::FAST && T::BLOCK >= 768) {
+            // The library-tree kernel reads these rows from LDS only (no global side in its accessors: head of
+            // render_kernel); a world whose rows do not fit is walked by the reference-tree kernel.
+            const bool fits = a.lds_nodes && (sc.n_mspheres == 0 || (sc.lds_mspheres != kNone && sc.lds_msphere_aux != kNone)) &&
+                              (sc.n_spheres == 0 || (sc.lds_spheres_tab != kNone && sc.lds_sphere_aux != kNone)) &&
+                              (sc.n_materials == 0 || sc.lds_materials != kNone);
+            if (!fits) return launch_one<TBvhPrims>(sc_in, a_in, stream, info);
+            auto empty = [](uint32_t &slot) { if (slot == kNone) slot = 0; };  // an empty table is never read
+            empty(sc.lds_mspheres); empty(sc.lds_msphere_aux); empty(sc.lds_spheres_tab); empty(sc.lds_sphere_aux); empty(sc.lds_materials);
         }
         if (T::COMPOSITE) {
             // Small tables ride along behind the node rows, each on its own merits: the records a leaf test or the shading
@@ -2982,6 +3006,20 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
                 place(sc.lds_boxes, b_boxes, 16 * 1024);
             }
             lds = off;
+            if constexpr (T::BATCH && T::BLOCK >= 768) {
+                // The deep kernel reads its node rows and every table from LDS only (its accessors have no global side: see
+                // the head of render_kernel).  A scene that does not fit goes to the general kernel, which reads what is
+                // not staged from L2.
+                const bool fits = a.lds_nodes && (sc.n_objects == 0 || sc.lds_objects != kNone) && (sc.n_xforms == 0 || sc.lds_xforms != kNone) &&
+                                  (sc.n_media == 0 || sc.lds_media != kNone) && (sc.n_group_boxes == 0 || sc.lds_group_boxes != kNone) &&
+                                  (sc.n_materials == 0 || sc.lds_materials != kNone) && (sc.n_perlin == 0 || sc.lds_perlin != kNone) &&
+                                  (sc.n_boxes == 0 || sc.lds_boxes != kNone) && (sc.n_spheres == 0 || sc.lds_spheres_tab != kNone);
+                // (the quad rows stay optional: a box's six faces are read only for a hit point on one of its edges)
+                if (!fits) return launch_one<TBvhGeneral>(sc_in, a_in, stream, info);
+                auto empty = [](uint32_t &slot) { if (slot == kNone) slot = 0; };  // an empty table is never read
+                empty(sc.lds_objects); empty(sc.lds_xforms); empty(sc.lds_media); empty(sc.lds_group_boxes); empty(sc.lds_materials);
+                empty(sc.lds_perlin); empty(sc.lds_boxes); empty(sc.lds_spheres_tab);
+            }
         }
     } else if (T::WORLD == 2) {
         lds = (T::BLOCK / 64) * kQueueCap * 64 * sizeof(uint16_t);

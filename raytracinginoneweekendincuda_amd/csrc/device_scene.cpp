@@ -419,10 +419,11 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     //  * BVH worlds, heaviest tiles first: the 8x8 tiles are ranked by rays traced and the pixel queue hands them out in
     //    that order (in row-major order C3's queue drained at 38 ms and the last wave left at 99 ms);
     //  * sphere-list and primitive-BVH worlds, heavy and light pixels: the few pixels with long chains (0.4 % of C2's
-    //    trace more than 10 rays per sample, up to 41) are listed and rendered by a launch of their own, started first on
-    //    a second stream, in which a wave holds only a few pixels -- the lanes share each ray's scan (sphere list: a
-    //    third of the latency per ray at 1.8x the work), or simply have the wave to themselves (BVH walk) -- while the other
-    //    launch skips them.  C2 took 367 ms where its throughput alone needs ~310; 338 ms with the two launches.
+    //    trace more than 10 rays per sample, up to 41) are listed; two waves of every workgroup serve that list first, a
+    //    few pixels at a time -- the lanes share each ray's scan (sphere list: a third of the latency per ray at 1.8x the
+    //    work), or simply have the wave to themselves (BVH walk) -- and then join the tile queue, whose pixels skip the
+    //    listed ones.  (The first form, a launch of its own for the list on a second stream, is still there for
+    //    RTOW_ROLES=0.)  C2 took 367 ms where its throughput alone needs ~310.
     // Every pixel is still rendered exactly once from its own stream: the frame is the same bit for bit
     // (tests: ...tile_ranking..., ...heavy_and_light...; RT_FLAG_ROW_MAJOR_TILES / RT_FLAG_NO_PIXEL_CLASSES turn them off).
     const bool bvh_kernel = (f.last_kernel.kind & 63) < 8;

@@ -177,6 +177,9 @@ typedef struct rt_render_params {
 #define RT_FLAG_EXACT_SCAN 256u      /* sphere-list worlds: every ray runs the reference's discriminant against every sphere (default: a cheaper
                                       conservative filter rejects the spheres a ray's line misses and only the survivors go through the
                                       reference's arithmetic; the image is the same bit for bit either way) */
+#define RT_FLAG_ACCELERATE_LISTS 512u /* HittableList worlds of primitives only (no leaf draws random numbers): render through the library's
+                                      own tree as a BvhNode world would be -- the reference's "BVH image == list image" invariant the other
+                                      way round; off by default so that a list world is scanned as the reference scans it */
 #define RT_FLAG_ROW_MAJOR_TILES 16u /* BVH worlds: keep the pixel queue in row-major tile order (default: a short rehearsal ranks
                                       the 8x8 tiles by rays traced and the heaviest start first; the image is the same either way) */
 

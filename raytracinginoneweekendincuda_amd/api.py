@@ -25,6 +25,7 @@ FLAG_OVERDUE_PRIORITY = 4   # diagnostics
 FLAG_ACCUMULATE = 8         # with KEEP_RNG_STATE: add this launch's samples to the film's running sums
 FLAG_ROW_MAJOR_TILES = 16   # BVH worlds: keep the pixel queue in row-major tile order (no cost ranking)
 FLAG_ALWAYS_WALK = 32       # small BVH worlds: walk the tree instead of scanning all leaves
+FLAG_ACCELERATE_LISTS = 512  # list worlds of primitives: render through the library's tree (default: scan the list as the reference does)
 FLAG_EXACT_SCAN = 256       # sphere-list worlds: the reference's discriminant for every sphere (default: conservative filter first)
 FLAG_REFERENCE_TREE = 128   # primitive BVH worlds: walk the reference's own tree (default: the library's SAH tree)
 FLAG_NO_PIXEL_CLASSES = 64  # sphere-list worlds: one launch for all pixels (no separate launch for the long-chain pixels)

@@ -403,6 +403,7 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.always_walk = (p->flags & RT_FLAG_ALWAYS_WALK) ? 1 : 0;
     ra.reference_tree = (p->flags & RT_FLAG_REFERENCE_TREE) ? 1 : 0;
     ra.exact_scan = (p->flags & RT_FLAG_EXACT_SCAN) ? 1 : 0;
+    ra.accelerate_lists = (p->flags & RT_FLAG_ACCELERATE_LISTS) ? 1 : 0;
     if (const char *e = std::getenv("RTOW_EXACT_SCAN")) ra.exact_scan = std::atoi(e);
     if (const char *e = std::getenv("RTOW_HEAVY_SCAN")) ra.heavy_scan = std::atoi(e);
     ra.small_world = 64;  // scan budget in half sphere tests, see FlatScene::scan_cost

@@ -2935,6 +2935,19 @@ using TListPrims = Traits<1, false, false, 4>;  // 127-129 VGPRs without the bou
 #endif
 using TListInstances = Traits<1, true, false, RT_WAVES_LIST_INSTANCES, false>;
 
+// Do the node rows and the sphere / material rows of a primitive world fit the library-tree kernel's LDS?  (The same sums as
+// launch_one<TBvhPrimsFast>'s placement, for callers that have no reference tree to fall back to.)
+[[maybe_unused]] static bool fast_rows_fit(const DeviceScene &sc)
+{
+    auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t nodes = (size_t)sc.n_fast_nodes * kFastNodeBytes;
+    if (nodes > 60 * 1024) return false;
+    const size_t rows = up(nodes) + up((size_t)sc.n_mspheres * sizeof(MSphereGeom)) + up((size_t)sc.n_mspheres * sizeof(SphereAux)) +
+                        up((size_t)sc.n_spheres * sizeof(SphereGeom)) + up((size_t)sc.n_spheres * sizeof(SphereAux)) +
+                        up((size_t)sc.n_materials * sizeof(MaterialRec));
+    return rows + 5 * 64 <= 158 * 1024;
+}
+
 template <class T>
 hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream, KernelInfo *info)
 {
@@ -3093,6 +3106,10 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
     auto composite_kernel = [&](int which) { return RT_CAT(launch_composite_, RT_SUFFIX)(which, sc, a, stream, info); };
     const bool composite = sc.n_objects != 0 || sc.n_boxes != 0;
     const bool rich = (sc.flags & SCENE_RICH_TEXTURES) != 0;
+    // RT_FLAG_ACCELERATE_LISTS: a list world of primitives through the library's tree, when its rows fit the kernel's LDS
+    if (a.accelerate_lists && sc.world_kind == WORLD_LIST && sc.fast_nodes && !composite && !rich && !(sc.flags & SCENE_HAS_MEDIA) &&
+        !(sc.flags & SCENE_HAS_TREES) && !a.force_general && fast_rows_fit(sc))
+        return launch_one<TBvhPrimsFast>(sc, a, stream, info);
     if ((sc.flags & SCENE_LIST_ALL_SPHERES) && !rich && sc.n_spheres <= 65535u && !a.force_general)
         return launch_one<TSphereList>(sc, a, stream, info);
     if (sc.flags & SCENE_HAS_TREES) return composite_kernel(sc.world_kind == WORLD_BVH ? CK_BVH_NESTED : CK_LIST_NESTED);

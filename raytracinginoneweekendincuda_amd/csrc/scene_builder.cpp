@@ -824,7 +824,8 @@ static void build_fast_tree(FlatScene &f)
 {
     f.fast_nodes.clear();
     const size_t n = f.world_items.size();
-    if (f.world_kind != WORLD_BVH || n < 3 || n > 40000 || !f.objects.empty() || !f.boxes.empty() || !f.tree_nodes.empty()) return;
+    // (built for list worlds of primitives as well: RT_FLAG_ACCELERATE_LISTS renders them through it)
+    if (n < 3 || n > 40000 || !f.objects.empty() || !f.boxes.empty() || !f.tree_nodes.empty()) return;
     for (uint32_t ref : f.world_items) {
         const uint32_t tag = ref >> kRefShift;
         if (tag != REF_SPHERE && tag != REF_MSPHERE && tag != REF_QUAD) return;

@@ -152,6 +152,7 @@ int main(int argc, char **argv)
 {
     int width = 1440, height = 720, scene_id = 9, spp = -1, depth = 50, world_kind = 0, variant = 1, device = 0, gpus = 0;
     unsigned long long seed = 1984;
+    unsigned flags = 0;          // RT_FLAG_* bits (schedulers and the opt-in list acceleration; none changes the picture)
     std::string out = "output.ppm";
     std::string earth_path;      // decoded 8-bit sRGB pixels of the earth texture (P6): converted like RtwImage::Load does
     bool earth_is_bytes = false; // --earth-bytes: the file already holds what RtwImage::Load hands to ImageTexture
@@ -171,6 +172,8 @@ int main(int argc, char **argv)
         else if (const char *v = val("--variant")) variant = std::strcmp(v, "strict") == 0 ? 0 : 1;
         else if (const char *v = val("--device")) device = std::atoi(v);
         else if (const char *v = val("--gpus")) gpus = std::atoi(v);  // >= 1: stripe the frame over that many GPUs + one RCCL gather
+        else if (const char *v = val("--flags")) flags = (unsigned)std::strtoul(v, nullptr, 0);
+        else if (a == "--accelerate-lists") flags |= RT_FLAG_ACCELERATE_LISTS;
         else if (const char *v = val("--output")) out = v;
         else if (const char *v = val("--earth")) earth_path = v;
         else if (const char *v = val("--earth-bytes")) {
@@ -180,10 +183,12 @@ int main(int argc, char **argv)
             std::fprintf(stderr,
                          "usage: rtow [--scene 0..11] [--width W] [--height H] [--spp N] [--depth D] [--seed S]\n"
                          "            [--world bvh|list] [--variant strict|fast] [--device N] [--gpus N] [--output file.ppm]\n"
-                         "            [--earth decoded.ppm | --earth-bytes texture.ppm]\n"
+                         "            [--earth decoded.ppm | --earth-bytes texture.ppm] [--accelerate-lists] [--flags N]\n"
                          "  --earth        binary PPM (P6) of earthmap.jpg as decoded to 8-bit sRGB (e.g. `djpeg earthmap.jpg`); it is\n"
                          "                 linearised and re-quantised exactly as the reference's RtwImage::Load does\n"
-                         "  --earth-bytes  binary PPM (P6) that already holds the bytes RtwImage::Load hands to ImageTexture\n");
+                         "  --earth-bytes  binary PPM (P6) that already holds the bytes RtwImage::Load hands to ImageTexture\n"
+                         "  --accelerate-lists  render a list world of primitives through the library's tree (same picture, faster)\n"
+                         "  --flags        RT_FLAG_* bits of include/rtow.h (none of them changes the picture)\n");
             return 2;
         }
     }
@@ -231,6 +236,7 @@ int main(int argc, char **argv)
     p.world_size = 1;
     p.variant = variant;
     p.device = device;
+    p.flags = flags;
     std::vector<double> frame((size_t)width * height * 3);
     rt_render_stats st{};
     auto t0 = std::chrono::steady_clock::now();

@@ -1284,6 +1284,9 @@ constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenev
 #ifndef RT_STAMP
 #define RT_STAMP 0  // diagnostic build: wall-clock stamps of queue exhaustion / first and last wave exit
 #endif
+#ifndef RT_FAST_VISITS
+#define RT_FAST_VISITS 2  // node visits of the library-tree walk per look at the wave's state
+#endif
 #ifndef RT_BURST
 #define RT_BURST 8
 #endif
@@ -1293,6 +1296,8 @@ constexpr int kQueueCap = 16;   // entries per lane; the queue is drained whenev
 constexpr int kBurst = RT_BURST;    // BVH worlds: at most this many node visits between two leaf phases
 constexpr int kRounds = RT_ROUNDS;  // node/leaf phase pairs per look at the shading queue, primitive worlds
 constexpr int kRoundsComposite = 4; // the same for composite worlds
+constexpr int kRoundsFast = 4;      // and for the library-tree kernel, whose frame ends with its long pixels: they are shaded sooner
+                                    // (C3, one call: 2 rounds 2615, 3: 2711, 4: 2891-2943, 5: 2805, 6: 2784, 8: 2675 Msamples/s)
 
 DEV void drain_queue(const SphereGeom *__restrict__ spheres, const uint16_t *queue, uint32_t lane, uint32_t &count,
                      const Ray &r, double a, double tmin, double &closest, uint32_t &best_k)
@@ -2586,7 +2591,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             // many lanes at once instead of trailing every node visit with a few.
             // node/leaf phase pairs per look at the shading queue: measured optimum 6 for primitive worlds (C3: 8 -> 6 is
             // +7 %, 4 is -1 %), 4 for composite ones (C5: +6 %; C4 indifferent)
-            const int n_rounds = T::BATCH ? a.rounds : (T::COMPOSITE ? kRoundsComposite : kRounds);
+            const int n_rounds = T::BATCH ? a.rounds : (T::COMPOSITE ? kRoundsComposite : (T::FAST ? kRoundsFast : kRounds));
             for (int round = 0; round < n_rounds; round++) {
                 for (int step = 0; step < (T::COMPOSITE ? a.node_burst : kBurst); step++) {
                     const bool mover = walk_moving(walk.state);
@@ -2605,6 +2610,9 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                             if constexpr (T::FAST) {
                                 walk_node_fast(ray, 0.001, walk);
                                 if (walk_moving(walk.state)) walk_node_fast(ray, 0.001, walk);
+#if RT_FAST_VISITS >= 3
+                                if (walk_moving(walk.state)) walk_node_fast(ray, 0.001, walk);
+#endif
                             } else
                             walk_node<T::BATCH>(nv, ray, 0.001, walk);
                             // Primitive worlds (deep BVH, cheap leaves): a second visit before the next look at the

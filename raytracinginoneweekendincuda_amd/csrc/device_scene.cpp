@@ -451,7 +451,9 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     if (prim_bvh_kernel && !roles_in_one_launch && !std::getenv("RTOW_PIXEL_CLASSES")) split = false;
     if (const char *e = std::getenv("RTOW_ROLES")) roles_in_one_launch = std::atoi(e) != 0;  // experiments only
     if (rank_tiles || split) {
-        int probe_spp = split ? 4 : p->samples_per_pixel / 100;
+        // sphere-list frames of 400 samples and more rehearse 8: the heavy pixels are told apart more reliably (C2, three
+        // interleaved pairs in one call: 1859-1893 with 4, 1908-1918 with 8; the primitive-BVH kernel is better off with 4)
+        int probe_spp = split ? ((list_kernel && p->samples_per_pixel >= 400) ? 8 : 4) : p->samples_per_pixel / 100;
         probe_spp = probe_spp < 1 ? 1 : (probe_spp > 8 ? 8 : probe_spp);
         if (const char *e = std::getenv("RTOW_PROBE_SPP")) probe_spp = std::atoi(e);  // experiments only
         if (probe_spp > p->samples_per_pixel) probe_spp = p->samples_per_pixel;

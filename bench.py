@@ -150,8 +150,8 @@ def measured_issue(workload, spp, variant):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed frames (default 3; C5, 31 s a frame: 1)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames first (default 1; C5: 0)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", default="auto", choices=["auto", "strict", "fast"],
                     help="auto = the strict build (the reference's arithmetic, bit-identical frames) for C2 and C3, where it is within "
@@ -171,11 +171,18 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="RT_FLAG_* tuning/diagnostic bits")
     ap.add_argument("--shade-batch", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="tuning knob: cap resident workgroups per CU")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=None,
                     help="after the headline (one frame after another) also time the same K frames with this many in "
                          "flight on per-film streams and report it as \"pipelined\" (1 GPU only; 1 = skip)")
     ap.add_argument("--overdue", type=int, default=0, help="tuning knob: rays/sample budget before a pixel goes cooperative")
     args = ap.parse_args()
+    long_frames = args.workload == "c5" and not args.spp   # 31 s a frame at the full 5000 spp
+    if args.steps is None:
+        args.steps = 1 if long_frames else 3
+    if args.warmup is None:
+        args.warmup = 0 if long_frames else 1
+    if args.pipeline is None:
+        args.pipeline = 1 if long_frames else 2
 
     import torch
     import raytracinginoneweekendincuda_amd as rt

@@ -532,6 +532,27 @@ def test_rtow_executable_takes_the_earth_texture(earth, tmp_path):
     assert hashlib.md5(c.read_bytes()).hexdigest() == hashlib.md5(b.read_bytes()).hexdigest()
 
 
+def test_rtow_executable_list_world_flags(tmp_path):
+    """`rtow --world list` scans the list as the reference does; `--accelerate-lists` (RT_FLAG_ACCELERATE_LISTS) and `--flags`
+    (here RT_FLAG_EXACT_SCAN = 256) change how it is searched, never the picture: three identical output files."""
+    import hashlib
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(rt.library_path()), "rtow")
+    args = ["--scene", "11", "--world", "list", "--width", "160", "--height", "96", "--spp", "8", "--variant", "strict"]
+    digests = []
+    for k, extra in enumerate(([], ["--accelerate-lists"], ["--flags", "256"])):
+        out = tmp_path / f"o{k}.ppm"
+        r = subprocess.run([exe, *args, *extra, "--output", str(out)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        digests.append(hashlib.md5(out.read_bytes()).hexdigest())
+    assert digests[0] == digests[1] == digests[2]
+    frame, _ = rt.builtin_scene(11, 1, 160, 96).render(160, 96, 8, variant=0)
+    ref = tmp_path / "api.ppm"
+    rt.write_ppm(ref, frame)
+    assert hashlib.md5(ref.read_bytes()).hexdigest() == digests[0]
+
+
 @pytest.mark.parametrize("scene_id", [0, 11])
 @pytest.mark.parametrize("variant", [0])
 def test_thin_wave_scan_of_a_sphere_bvh_world_equals_the_walk(oracle, scene_id, variant):

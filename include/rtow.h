@@ -56,6 +56,13 @@ RTOW_API rt_rng *rt_rng_create_salted(uint64_t seed, uint64_t sequence, int salt
 /* ---- scene lifetime ---- */
 RTOW_API rt_scene *rt_scene_create(void);
 RTOW_API void rt_scene_destroy(rt_scene *scene);                   /* replaces FreeWorld, R/kernel.cu:548-568 */
+/* Destroying a scene while launches of it are in flight is allowed: the call first waits for every such launch (the
+ * kernels read the scene's tables); the films stay valid and their rt_render_finish reports as usual. */
+/* Options read by the next rt_scene_commit (tests and timing; none changes an image). */
+#define RT_SCENE_PLAIN_QUADS 1u          /* every quad takes the general test of R/Quad.h:52-99 (default: quads along the coordinate
+                                            axes drop the terms that are exact zeros; MakeBox boxes are tested as boxes) */
+#define RT_SCENE_REFERENCE_TREE_ONLY 2u  /* do not build the library's own tree for primitive worlds: only the reference's */
+RTOW_API int rt_scene_set_options(rt_scene *scene, uint32_t options);
 
 /* ---- textures (R/Texture.h) ---- */
 RTOW_API rt_handle rt_solid_color(rt_scene *s, double r, double g, double b);                 /* :38,:43 */
@@ -146,7 +153,12 @@ typedef struct rt_render_params {
     uint64_t seed;                /* literal 1984 at R/kernel.cu:118 */
     int32_t stripe_rows;          /* multi-GPU: rows are dealt in stripes of this many rows ... */
     int32_t rank, world_size;     /* ... stripe k belongs to rank k % world_size.  1 GPU: rank 0 of 1 */
-    int32_t variant;              /* 0 = strict (no FMA contraction; bit-comparable with the CPU oracle), 1 = fast */
+    int32_t variant;              /* 0 = strict: no FMA contraction, the reference's arithmetic operation by operation; frames equal the CPU
+                                     oracle's bit for bit -- the build to use where the north star's 1e-5 tolerance matters.
+                                     1 = fast: FMA contraction, 0-3 % faster.  A contracted comparison that falls the other way re-draws
+                                     the rest of that pixel's random stream: rare at a few hundred samples on surface scenes (C2-C4:
+                                     >= 0.9998 of the pixels within 1e-5), but on media scenes at thousands of samples per pixel most
+                                     pixels leave the tolerance (C5 at 5000 spp: 0.24-0.75 within 1e-5; still a correct image) */
     int32_t device;               /* HIP device ordinal */
     int32_t flags;                /* RT_FLAG_* */
     void *stream;                 /* hipStream_t to launch on (NULL = the film's own stream) */
@@ -154,9 +166,11 @@ typedef struct rt_render_params {
     int32_t overdue_rays_per_sample; /* tuning: a pixel past this many rays/sample advances in extra cooperative passes (0 or <0 = never, the default) */
     int32_t shade_batch;          /* tuning: BVH kernels shade once this many lanes finished traversal (0 = default 16) */
     int32_t max_blocks_per_cu;    /* tuning: cap on resident 256-thread workgroups per CU (0 = as many as fit) */
-    int32_t pixels_per_wave;      /* sphere-list worlds: pixels a wave works on at a time, 1..64 (0 = chosen from the pixels this rank owns).
-                                     Fewer than 64 leaves lanes free to share each ray's scan (64 / pixels lanes per ray): the same frame,
-                                     a shorter chain per pixel -- what a small frame, or one rank's share of a frame, needs */
+    int32_t pixels_per_wave;      /* list worlds (HittableList worlds and small BVH worlds rendered as lists; no media): pixels a wave works
+                                     on at a time, a power of two 1..64; the wave's other lanes share each ray's leaf tests (64 / pixels
+                                     lanes per ray): the same frame bit for bit, a shorter chain per pixel -- what a small frame, or one
+                                     rank's share of a frame, needs.  0 = chosen by the library from the pixels this film owns and the
+                                     lanes the device holds (64 whenever there are pixels enough to fill them) */
     int32_t reserved0;
 } rt_render_params;
 
@@ -173,13 +187,18 @@ typedef struct rt_render_params {
                                       tile queue skips them; the image is the same either way) */
 #define RT_FLAG_REFERENCE_TREE 128u  /* BVH worlds of primitives only are walked through the library's own tree (surface-area heuristic, near
                                       child first) -- no leaf draws random numbers there, so the closest hit is the one the reference's tree
-                                      gives; this flag walks the reference's own tree in its own order instead (tests, timing) */
+                                      gives; this flag walks the reference's own tree in its own order instead (tests, timing).  A world in
+                                      which two primitives coincide (identical spheres, overlapping quads in one plane) has no library
+                                      tree at all: there the order of the tests decides which of the two a ray sees */
 #define RT_FLAG_EXACT_SCAN 256u      /* sphere-list worlds: every ray runs the reference's discriminant against every sphere (default: a cheaper
                                       conservative filter rejects the spheres a ray's line misses and only the survivors go through the
                                       reference's arithmetic; the image is the same bit for bit either way) */
 #define RT_FLAG_ACCELERATE_LISTS 512u /* HittableList worlds of primitives only (no leaf draws random numbers): render through the library's
                                       own tree as a BvhNode world would be -- the reference's "BVH image == list image" invariant the other
-                                      way round; off by default so that a list world is scanned as the reference scans it */
+                                      way round; off by default so that a list world is scanned as the reference scans it.  Ignored for
+                                      a list with coincident primitives (see RT_FLAG_REFERENCE_TREE) */
+#define RT_FLAG_COOP_SINGLE 1024u    /* tests: sphere-list worlds, thin waves scan one ray at a time with all 64 lanes (the older scheme)
+                                      instead of several rays in groups of lanes */
 #define RT_FLAG_ROW_MAJOR_TILES 16u /* BVH worlds: keep the pixel queue in row-major tile order (default: a short rehearsal ranks
                                       the 8x8 tiles by rays traced and the heaviest start first; the image is the same either way) */
 
@@ -193,7 +212,7 @@ typedef struct rt_render_stats {
     uint32_t kernel_vgprs;
     uint32_t lds_bytes;
     uint32_t kernel_kind;         /* which instantiation ran: world*4 + composite*2 + rich (world 0 bvh, 1 list, 2 sphere list) */
-    uint32_t reserved;
+    uint32_t pixels_per_wave;     /* what rt_render_params.pixels_per_wave came to for this launch (64 = one lane per ray) */
 } rt_render_stats;
 
 /* Rows owned by (rank, world_size) for a height: returns count, fills rows_out (ascending j) if non-NULL. */

@@ -15,11 +15,11 @@ for i, st in enumerate(idx[1:]):
         if m: cur[m.group(1)] = m.group(2)
         if line.startswith('.wavefront_size'):
             n = cur.get('name', '')
-            m = re.search(r'render_kernelILi(\d)ENS_12_GLOBAL__N_16TraitsILi(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)', n)
+            m = re.search(r'render_kernelILi(\d)ENS_12_GLOBAL__N_16TraitsILi(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELb(\d)ELb(\d)', n)
             if m:
-                strict, world, comp, rich, waves, media, batch, nested, block, fast = (int(x) for x in m.groups())
-                rows.append((world, comp, rich, media, batch, nested, fast, block, waves, 'strict' if strict else 'fast',
+                strict, world, comp, rich, waves, media, batch, nested, block, fast, grouped = (int(x) for x in m.groups())
+                rows.append((world, comp, rich, media, batch, nested, fast, grouped, block, waves, 'strict' if strict else 'fast',
                              int(cur['vgpr_count']), int(cur['private_segment_fixed_size']), int(cur['vgpr_spill_count'])))
             cur = {}
-print("world comp rich media batch nested fast block waves build vgpr scratchB spills")
+print("world comp rich media batch nested fast grouped block waves build vgpr scratchB spills")
 for r in sorted(rows): print(*r)

@@ -20,7 +20,7 @@ class RenderStats(C.Structure):
     _fields_ = [
         ("samples", C.c_uint64), ("rays", C.c_uint64), ("seconds_seed", C.c_double), ("seconds_render", C.c_double),
         ("pixels", C.c_uint32), ("rows", C.c_uint32), ("kernel_vgprs", C.c_uint32), ("lds_bytes", C.c_uint32),
-        ("kernel_kind", C.c_uint32), ("reserved", C.c_uint32),
+        ("kernel_kind", C.c_uint32), ("pixels_per_wave", C.c_uint32),
     ]
 
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     "rt_rng_state": (None, [P, C.POINTER(C.c_uint32)]),
     "rt_scene_create": (P, []),
     "rt_scene_destroy": (None, [P]),
+    "rt_scene_set_options": (I, [P, C.c_uint32]),
     "rt_solid_color": (H, [P, D, D, D]),
     "rt_checker_texture": (H, [P, D, H, H]),
     "rt_image_texture": (H, [P, P, I, I]),

@@ -28,7 +28,13 @@ FLAG_ALWAYS_WALK = 32       # small BVH worlds: walk the tree instead of scannin
 FLAG_ACCELERATE_LISTS = 512  # list worlds of primitives: render through the library's tree (default: scan the list as the reference does)
 FLAG_EXACT_SCAN = 256       # sphere-list worlds: the reference's discriminant for every sphere (default: conservative filter first)
 FLAG_REFERENCE_TREE = 128   # primitive BVH worlds: walk the reference's own tree (default: the library's SAH tree)
+FLAG_COOP_SINGLE = 1024     # tests: sphere-list worlds, thin waves scan one ray at a time (the older scheme)
 FLAG_NO_PIXEL_CLASSES = 64  # sphere-list worlds: one launch for all pixels (no separate launch for the long-chain pixels)
+
+
+# rt_scene_set_options (read by the next commit)
+SCENE_PLAIN_QUADS = 1           # every quad takes the general test; boxes stay lists of six quads
+SCENE_REFERENCE_TREE_ONLY = 2   # no library tree for primitive worlds
 
 
 def lib():
@@ -90,6 +96,9 @@ class Scene:
         if getattr(self, "_p", None):
             lib().rt_scene_destroy(self._p)
             self._p = None
+
+    def set_options(self, options):
+        _check(lib().rt_scene_set_options(self._p, options))
 
     # ---- textures (R/Texture.h) ----
     def SolidColor(self, c):
@@ -263,8 +272,9 @@ class Film:
 
     def __del__(self):
         if getattr(self, "_p", None):
-            lib().rt_film_destroy(self._p)
+            lib().rt_film_destroy(self._p)   # waits for a launch still in flight
             self._p = None
+        self._scene = None
 
     def params(self, spp, max_depth=50, seed=1984, variant=0, flags=0, stream=None, coop_threshold=0, overdue=0,
                shade_batch=0, max_blocks_per_cu=0, pixels_per_wave=0):
@@ -274,10 +284,15 @@ class Film:
 
     def launch(self, scene, params):
         _check(lib().rt_render_launch(scene._p, self._p, C.byref(params)))
+        self._scene = scene   # the kernel reads the scene's tables: keep it alive until finish()
 
-    def finish(self, scene):
+    def finish(self, scene=None):
         st = RenderStats()
-        _check(lib().rt_render_finish(scene._p, self._p, C.byref(st)))
+        scene = scene if scene is not None else getattr(self, "_scene", None)
+        try:
+            _check(lib().rt_render_finish(scene._p if scene is not None else None, self._p, C.byref(st)))
+        finally:
+            self._scene = None
         return st
 
     def render(self, scene, spp, **kw):

@@ -93,6 +93,28 @@ static int select_device(int device)
 
 constexpr size_t kCounterWords = 128;
 
+// Scheduling constants are fixed in the shipping library: it reads nothing from the environment on the launch path.
+// A/B builds (make EXTRA=-DRT_TUNING=1 LIBNAME=..., loaded through RTOW_LIB_PATH by the Python binding) compile the
+// overrides in; every override is clamped to the range the kernels accept (a zero pixels-per-wave or round count would
+// leave the persistent waves spinning).  None of them changes an image.
+#ifndef RT_TUNING
+#define RT_TUNING 0
+#endif
+#if RT_TUNING
+static int tune(const char *name, int value, int lo, int hi)
+{
+    if (const char *e = std::getenv(name)) {
+        const int v = std::atoi(e);
+        value = v < lo ? lo : (v > hi ? hi : v);
+    }
+    return value;
+}
+static bool tune_set(const char *name) { return std::getenv(name) != nullptr; }
+#else
+static inline int tune(const char *, int value, int, int) { return value; }
+static inline bool tune_set(const char *) { return false; }
+#endif
+
 struct FilmImpl {
     int device = 0;
     int width = 0, height = 0, stripe_rows = 8, rank = 0, world_size = 1;
@@ -123,7 +145,47 @@ struct FilmImpl {
     uint64_t last_samples = 0;
     int last_variant = 0;
     KernelInfo last_kernel{};
+    int last_pixels_per_wave = 64;
 };
+
+// a launch of `s` into `f` is (about to be) in flight / is over
+static void mark_in_flight(SceneImpl &s, FilmImpl &f)
+{
+    f.in_flight = true;
+    f.scene_in_flight = &s;
+    s.launches_in_flight++;
+    s.films_in_flight.push_back(&f);
+}
+static void mark_done(FilmImpl &f)
+{
+    f.in_flight = false;
+    if (SceneImpl *s = f.scene_in_flight) {
+        s->launches_in_flight--;
+        for (size_t k = 0; k < s->films_in_flight.size(); k++)
+            if (s->films_in_flight[k] == &f) {
+                s->films_in_flight.erase(s->films_in_flight.begin() + (long)k);
+                break;
+            }
+        f.scene_in_flight = nullptr;
+    }
+}
+
+void wait_for_films_in_flight(SceneImpl &s)
+{
+    int prev = 0;
+    hipGetDevice(&prev);
+    for (void *p : s.films_in_flight) {
+        FilmImpl *f = static_cast<FilmImpl *>(p);
+        hipSetDevice(f->device);
+        // the whole stream, not only the last event: a launch that failed half-way has recorded no event
+        if (f->last_stream) hipStreamSynchronize(f->last_stream);
+        else if (f->ev[3]) hipEventSynchronize(f->ev[3]);
+        f->scene_in_flight = nullptr;  // the film stays "in flight" until its rt_render_finish, which then only reports
+    }
+    hipSetDevice(prev);
+    s.films_in_flight.clear();
+    s.launches_in_flight = 0;
+}
 
 } // namespace rtow
 
@@ -267,8 +329,8 @@ void rt_film_destroy(rt_film *film)
     FilmImpl *f = F(film);
     hipSetDevice(f->device);
     if (f->in_flight) {  // destroyed without rt_render_finish: wait for the kernel, give the scene its count back
-        if (f->ev[3]) hipEventSynchronize(f->ev[3]);
-        if (f->scene_in_flight) f->scene_in_flight->launches_in_flight--;
+        if (f->last_stream) hipStreamSynchronize(f->last_stream);
+        mark_done(*f);
     }
     if (f->own_pixels) hipFree(f->own_pixels);
     if (f->accum) hipFree(f->accum);
@@ -300,22 +362,10 @@ int rt_film_bind_pixels(rt_film *film, void *device_pixels)
     return RT_OK;
 }
 
-int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
+// Everything rt_render_launch puts on the stream: seeding, the rehearsal and its bookkeeping, the render kernel, the
+// counter copy.  Called with the film already marked in flight (a failure half-way leaves kernels running).
+static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, hipStream_t stream)
 {
-    if (!scene || !film || !p) return fail(RT_ERR_INVALID, "rt_render_launch: null argument");
-    SceneImpl &s = *S(scene);
-    FilmImpl &f = *F(film);
-    if (p->width != f.width || p->height != f.height || p->stripe_rows != f.stripe_rows || p->rank != f.rank ||
-        p->world_size != f.world_size || p->device != f.device)
-        return fail(RT_ERR_INVALID, "rt_render_launch: params do not match the film's geometry/device");
-    if (p->samples_per_pixel < 0 || p->max_depth < 0) return fail(RT_ERR_INVALID, "rt_render_launch: negative spp/depth");
-    if (p->variant != 0 && p->variant != 1) return fail(RT_ERR_INVALID, "rt_render_launch: variant must be 0 (strict) or 1 (fast)");
-    if (f.in_flight)
-        return fail(RT_ERR_STATE, "rt_render_launch: this film already has a render in flight (rt_render_finish it first; "
-                                  "use one film per frame in flight)");
-    if (int rc = rt_scene_upload(scene, f.device)) return rc;
-    if (int rc = select_device(f.device)) return rc;
-    hipStream_t stream = p->stream ? (hipStream_t)p->stream : f.own_stream;
     const bool keep = (p->flags & RT_FLAG_KEEP_RNG_STATE) && f.seeded;
 
     HIP_TRY(hipMemsetAsync(f.ray_counter, 0, kCounterWords * sizeof(unsigned long long), stream));
@@ -353,33 +403,24 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.ray_counter = f.ray_counter;
     ra.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 1);
     ra.coop_threshold = p->coop_threshold > 0 ? p->coop_threshold : 24;
-    ra.coop_single = 0;
-    if (const char *e = std::getenv("RTOW_COOP_SINGLE")) ra.coop_single = std::atoi(e);  // experiments only
+    ra.coop_single = (p->flags & RT_FLAG_COOP_SINGLE) ? 1 : 0;
     ra.num_cus = f.num_cus;
     ra.shade_batch = p->shade_batch > 0 ? p->shade_batch : 16;
     ra.max_blocks_per_cu = p->max_blocks_per_cu;
-    ra.pixels_per_wave = p->pixels_per_wave > 0 && p->pixels_per_wave < 64 ? p->pixels_per_wave : 64;
-    if (const char *e = std::getenv("RTOW_PIXELS_PER_WAVE")) ra.pixels_per_wave = std::atoi(e);  // experiments only
-    ra.boost_rounds = 8;
-    if (const char *e = std::getenv("RTOW_BOOST")) ra.boost_rounds = std::atoi(e);  // experiments only
-    ra.grid_blocks = 0;
-    if (const char *e = std::getenv("RTOW_GRID_BLOCKS")) ra.grid_blocks = std::atoi(e);  // experiments only
+    ra.pixels_per_wave = 64;  // settled below, once the kernel is known
+    ra.boost_rounds = tune("RTOW_BOOST", 8, 0, 1024);
+    ra.grid_blocks = tune("RTOW_GRID_BLOCKS", 0, 0, 1 << 20);
     if (ra.grid_blocks > 0) ra.max_blocks_per_cu = 8;
     // A deep world BVH over composite leaves (scene 9: 400 boxes, two media, an instanced cluster): a leaf phase costs
     // tens of node steps there, so it pays to wait until most walkers have parked.  A shallow one (Cornell box: 8
     // leaves) gains nothing from waiting.
     {
         const uint32_t world_nodes = s.flat.n_world_nodes;
-        ra.node_burst = world_nodes > 64 ? 24 : 8;
-        ra.park_ratio = world_nodes > 64 ? 4 : 1;
-        if (const char *e = std::getenv("RTOW_BURST")) ra.node_burst = std::atoi(e);  // experiments only
-        if (const char *e = std::getenv("RTOW_PARK")) ra.park_ratio = std::atoi(e);
-        ra.leaf_batch = 12;
-        ra.object_batch = 4;
-        ra.rounds = 4;
-        if (const char *e = std::getenv("RTOW_ROUNDS")) ra.rounds = std::atoi(e);
-        if (const char *e = std::getenv("RTOW_LEAF_BATCH")) ra.leaf_batch = std::atoi(e);
-        if (const char *e = std::getenv("RTOW_OBJECT_BATCH")) ra.object_batch = std::atoi(e);
+        ra.node_burst = tune("RTOW_BURST", world_nodes > 64 ? 24 : 8, 1, 4096);
+        ra.park_ratio = tune("RTOW_PARK", world_nodes > 64 ? 4 : 1, 1, 64);
+        ra.leaf_batch = tune("RTOW_LEAF_BATCH", 12, 1, 64);
+        ra.object_batch = tune("RTOW_OBJECT_BATCH", 4, 1, 64);
+        ra.rounds = tune("RTOW_ROUNDS", 4, 1, 64);
     }
     ra.overdue_priority = (p->flags & RT_FLAG_OVERDUE_PRIORITY) ? 1 : 0;
     {
@@ -402,18 +443,17 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     ra.force_general = (p->flags & RT_FLAG_FORCE_GENERAL) ? 1 : 0;
     ra.always_walk = (p->flags & RT_FLAG_ALWAYS_WALK) ? 1 : 0;
     ra.reference_tree = (p->flags & RT_FLAG_REFERENCE_TREE) ? 1 : 0;
-    ra.exact_scan = (p->flags & RT_FLAG_EXACT_SCAN) ? 1 : 0;
+    ra.exact_scan = tune("RTOW_EXACT_SCAN", (p->flags & RT_FLAG_EXACT_SCAN) ? 1 : 0, 0, 1);
     ra.accelerate_lists = (p->flags & RT_FLAG_ACCELERATE_LISTS) ? 1 : 0;
-    if (const char *e = std::getenv("RTOW_EXACT_SCAN")) ra.exact_scan = std::atoi(e);
-    if (const char *e = std::getenv("RTOW_HEAVY_SCAN")) ra.heavy_scan = std::atoi(e);
-    ra.small_world = 64;  // scan budget in half sphere tests, see FlatScene::scan_cost
-    if (const char *e = std::getenv("RTOW_SMALL_WORLD")) ra.small_world = std::atoi(e);  // experiments only
+    ra.heavy_scan = tune("RTOW_HEAVY_SCAN", 0, 0, 1);
+    ra.small_world = tune("RTOW_SMALL_WORLD", 64, 0, 1 << 20);  // scan budget in half sphere tests, see FlatScene::scan_cost
     const DeviceScene &ds = s.device[f.device]->scene;
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
+    const int kind = f.last_kernel.kind & 63;
     // BVH sphere worlds: thin waves may scan all leaves together instead of walking (scan_grouped_ms), but the planes
     // come from L2 and a chip full of thin waves scanning is bound by L2 bandwidth: measured slower than walking at every
     // threshold (C3: 1748 Msamples/s never, 1681 at 17, 1048 at 33).  Off unless asked for.
-    if ((f.last_kernel.kind & 63) < 8 && p->coop_threshold <= 0) ra.coop_threshold = 0;
+    if (kind < 8 && p->coop_threshold <= 0) ra.coop_threshold = 0;
     // A pixel's samples are one sequential chain (one RNG stream), so a frame cannot end before its longest pixel does
     // (glass: up to max_depth rays per sample).  One rehearsal of the first samples of every pixel -- the same RNG streams,
     // nothing written but ray counts, cost probe_spp / spp of the frame -- serves two schedulers:
@@ -424,38 +464,69 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     //    few pixels at a time -- the lanes share each ray's scan (sphere list: a third of the latency per ray at 1.8x the
     //    work), or simply have the wave to themselves (BVH walk) -- and then join the tile queue, whose pixels skip the
     //    listed ones.  (The first form, a launch of its own for the list on a second stream, is still there for
-    //    RTOW_ROLES=0.)  C2 took 367 ms where its throughput alone needs ~310.
+    //    tuning builds, RTOW_ROLES=0.)  C2 took 367 ms where its throughput alone needs ~310.
     // Every pixel is still rendered exactly once from its own stream: the frame is the same bit for bit
     // (tests: ...tile_ranking..., ...heavy_and_light...; RT_FLAG_ROW_MAJOR_TILES / RT_FLAG_NO_PIXEL_CLASSES turn them off).
-    const bool bvh_kernel = (f.last_kernel.kind & 63) < 8;
+    const bool bvh_kernel = kind < 8;
     bool rank_tiles = bvh_kernel && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 && !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
-    if (const char *e = std::getenv("RTOW_TILE_SORT")) rank_tiles = rank_tiles && std::atoi(e) != 0;  // experiments only
-    const bool list_kernel = (f.last_kernel.kind & 63) >= 16 && (f.last_kernel.kind & 63) < 32, prim_bvh_kernel = (f.last_kernel.kind & 63) == 0;
+    rank_tiles = rank_tiles && tune("RTOW_TILE_SORT", 1, 0, 1) != 0;
+    const bool sphere_list_kernel = kind >= 16 && kind < 32, prim_bvh_kernel = kind == 0;
+    const bool list_scan_kernel = kind == 8 || kind == 10;  // list scans without media: leaves can be dealt to lanes (render.hip scan_leaves_grouped)
     // the deep general kernel (one 768-thread workgroup per CU, C5): its ray chains are the longest of all (a ray takes ~140 us
     // in a full wave), which decides the frame whenever a GPU holds few pixels per lane -- a small frame, or one rank's share
-    const bool deep_kernel = (f.last_kernel.kind & 63) == 7 && f.last_kernel.lds_bytes > 64 * 1024;
+    const bool deep_kernel = kind == 7 && f.last_kernel.lds_bytes > 64 * 1024;
     // Measured and not adopted: with the fixed threshold most of C5's pixels through the mist and the glass count as heavy and
     // two server waves per workgroup take ten times as long over them (1/8 of the frame at 200 spp: 789 -> 1900 ms).
-    bool deep_roles = false;
-    if (const char *e = std::getenv("RTOW_ROLES_DEEP")) deep_roles = deep_kernel && std::atoi(e) != 0;  // experiments only
-    bool split = (list_kernel || prim_bvh_kernel || deep_roles) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
-                 f.n_pixels >= 65536u && p->pixels_per_wave <= 0 && !std::getenv("RTOW_PIXELS_PER_WAVE");
-    if (const char *e = std::getenv("RTOW_PIXEL_CLASSES")) split = split && std::atoi(e) != 0;  // experiments only
+    const bool deep_roles = deep_kernel && tune("RTOW_ROLES_DEEP", 0, 0, 1) != 0;
+    const bool ppw_given = (p->pixels_per_wave > 0 && p->pixels_per_wave < 64) || tune_set("RTOW_PIXELS_PER_WAVE");
+    bool split = (sphere_list_kernel || prim_bvh_kernel || deep_roles) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
+                 f.n_pixels >= 65536u && !ppw_given;
+    split = split && tune("RTOW_PIXEL_CLASSES", 1, 0, 1) != 0;
     // The primitive-BVH kernel on the reference's tree (256-thread workgroups) gained nothing from a second launch (C3
     // 1672 -> 1100-1200: opt-in); the library-tree kernel, whose 768-thread workgroup fills a CU, serves both classes in
     // ONE launch, by wave (RenderArgs::heavy_list): C3 2106 -> 2713 Msamples/s.
     // Sphere-list worlds: both forms work; serving the heavy pixels from two waves of every workgroup lets the launch keep
     // three workgroups per CU resident (a third wave per SIMD: +15 % in the steady state, which a frame whose end is set by
     // its long pixels could not use) -- C2 1479 (two launches, two workgroups per CU) -> 1556 Msamples/s.
-    bool roles_in_one_launch = (prim_bvh_kernel && (f.last_kernel.kind & 64) != 0) || deep_roles || list_kernel;
-    if (prim_bvh_kernel && !roles_in_one_launch && !std::getenv("RTOW_PIXEL_CLASSES")) split = false;
-    if (const char *e = std::getenv("RTOW_ROLES")) roles_in_one_launch = std::atoi(e) != 0;  // experiments only
+    bool roles_in_one_launch = (prim_bvh_kernel && (f.last_kernel.kind & 64) != 0) || deep_roles || sphere_list_kernel;
+    if (prim_bvh_kernel && !roles_in_one_launch && !tune_set("RTOW_PIXEL_CLASSES")) split = false;
+    roles_in_one_launch = tune("RTOW_ROLES", roles_in_one_launch ? 1 : 0, 0, 1) != 0;
+
+    // pixels_per_wave.  List scans (and the sphere list when it runs without pixel classes) can give a ray several lanes:
+    // with fewer pixels than the device has lanes -- a small frame, one rank's stripes of a frame -- every pixel's chain
+    // of rays gets shorter by it, and nothing else can shorten the frame (a pixel's samples are one sequential stream).
+    // 0 = automatic: as many pixels per wave as it takes to hand every pixel this film owns to a resident wave at once,
+    // as a power of two; 64 (one lane per ray) as soon as there are pixels enough for every lane.
+    {
+        int ppw = 64;
+        if (p->pixels_per_wave > 0 && p->pixels_per_wave < 64) {
+            ppw = p->pixels_per_wave;
+        } else if (p->pixels_per_wave <= 0 && (list_scan_kernel || (sphere_list_kernel && !split))) {
+            const int vg = f.last_kernel.vgprs > 0 ? f.last_kernel.vgprs : 128;
+            int waves_per_simd = 512 / ((vg + 7) & ~7);
+            waves_per_simd = waves_per_simd < 1 ? 1 : (waves_per_simd > 8 ? 8 : waves_per_simd);
+            const double resident_waves = (double)f.num_cus * 4.0 * waves_per_simd;
+            const double per_wave = (double)f.n_pixels / resident_waves;  // pixels a wave must hold for all to be in flight at once
+            while (ppw > 4 && (double)(ppw / 2) >= per_wave) ppw /= 2;
+        }
+        ppw = tune("RTOW_PIXELS_PER_WAVE", ppw, 1, 64);
+        if (list_scan_kernel) {  // the grouped leaf scan deals lanes in powers of two
+            int pow2 = 1;
+            while (pow2 * 2 <= ppw) pow2 *= 2;
+            ppw = pow2;
+        }
+        ra.pixels_per_wave = ppw;
+    }
+    f.last_pixels_per_wave = ra.pixels_per_wave;
+    if (ra.pixels_per_wave < 64 && list_scan_kernel)  // the instantiation that deals leaves to lanes: report that one
+        HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
+
     if (rank_tiles || split) {
         // sphere-list frames of 400 samples and more rehearse 8: the heavy pixels are told apart more reliably (C2, three
         // interleaved pairs in one call: 1859-1893 with 4, 1908-1918 with 8; the primitive-BVH kernel is better off with 4)
-        int probe_spp = split ? ((list_kernel && p->samples_per_pixel >= 400) ? 8 : 4) : p->samples_per_pixel / 100;
+        int probe_spp = split ? ((sphere_list_kernel && p->samples_per_pixel >= 400) ? 8 : 4) : p->samples_per_pixel / 100;
         probe_spp = probe_spp < 1 ? 1 : (probe_spp > 8 ? 8 : probe_spp);
-        if (const char *e = std::getenv("RTOW_PROBE_SPP")) probe_spp = std::atoi(e);  // experiments only
+        probe_spp = tune("RTOW_PROBE_SPP", probe_spp, 1, 64);
         if (probe_spp > p->samples_per_pixel) probe_spp = p->samples_per_pixel;
         if (split && !f.pix_cost) {
             HIP_TRY(hipMalloc((void **)&f.pix_cost, (size_t)f.n_pixels * sizeof(uint32_t)));
@@ -481,48 +552,40 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
         }
         HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, (light) queue cursor
         if (split) {
-            int heavy_rays_per_sample = list_kernel ? 10 : 12, heavy_ppw = list_kernel ? 4 : 6, heavy_blocks = list_kernel ? f.num_cus / 2 : f.num_cus, heavy_prio = 0;
-            if (const char *e = std::getenv("RTOW_HEAVY_RAYS")) heavy_rays_per_sample = std::atoi(e);  // experiments only, all four
-            if (const char *e = std::getenv("RTOW_HEAVY_PPW")) heavy_ppw = std::atoi(e);
-            if (const char *e = std::getenv("RTOW_HEAVY_BLOCKS")) heavy_blocks = std::atoi(e);
-            if (const char *e = std::getenv("RTOW_HEAVY_PRIO")) heavy_prio = std::atoi(e);
+            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", sphere_list_kernel ? 10 : 12, 1, 1 << 20);
+            int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6, 1, 64);
+            const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
+            // the serving waves' rays are the frame's critical path
+            const int heavy_prio = tune("RTOW_HEAVY_PRIO", (sphere_list_kernel && roles_in_one_launch) ? 3 : 0, 0, 3);
             HIP_TRY(hipMemsetAsync(f.heavy_count, 0, 64, stream));
             HIP_TRY(launch_classify_pixels(f.pix_cost, f.n_pixels, (uint32_t)(heavy_rays_per_sample * probe_spp), f.pix_class,
                                            f.heavy_list, f.heavy_count, stream));
             HIP_TRY(hipMemsetAsync(f.ray_counter + 6, 0, sizeof(unsigned long long), stream));  // heavy queue cursor
-            if (!roles_in_one_launch) {
-                HIP_TRY(hipEventRecord(f.ev_aux[0], stream));
-                HIP_TRY(hipStreamWaitEvent(f.aux_stream, f.ev_aux[0], 0));
-            }
             if (roles_in_one_launch) {
-                int heavy_waves = 2;
-                if (list_kernel) {
-                    if (!std::getenv("RTOW_HEAVY_PPW")) heavy_ppw = 8;
-                    if (!std::getenv("RTOW_HEAVY_PRIO")) heavy_prio = 3;  // the serving waves' rays are the frame's critical path
-                    if (ra.max_blocks_per_cu <= 0) ra.max_blocks_per_cu = 3;
-                }
-                if (const char *e = std::getenv("RTOW_HEAVY_WAVES")) heavy_waves = std::atoi(e);  // experiments only
+                if (sphere_list_kernel && ra.max_blocks_per_cu <= 0) ra.max_blocks_per_cu = 3;
                 ra.heavy_list = f.heavy_list;
                 ra.heavy_count = f.heavy_count;
                 ra.heavy_cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
-                ra.heavy_waves = heavy_waves;
+                ra.heavy_waves = tune("RTOW_HEAVY_WAVES", 2, 0, 12);
                 ra.heavy_ppw = heavy_ppw;
                 ra.heavy_priority = heavy_prio;
                 ra.pix_class = f.pix_class;
             } else {
-            RenderArgs heavy = ra;
-            heavy.tile_order = nullptr;
-            heavy.pixel_list = f.heavy_list;
-            heavy.pixel_list_count = f.heavy_count;
-            heavy.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
-            heavy.pixels_per_wave = heavy_ppw;
-            if (list_kernel) heavy.coop_threshold = 65;  // always the grouped scan
-            heavy.grid_blocks = heavy_blocks;
-            heavy.max_blocks_per_cu = 8;
-            heavy.wave_priority = heavy_prio;
-            HIP_TRY(p->variant ? launch_render_fast(ds, heavy, f.aux_stream) : launch_render_strict(ds, heavy, f.aux_stream));
-            HIP_TRY(hipEventRecord(f.ev_aux[1], f.aux_stream));
-            ra.pix_class = f.pix_class;
+                HIP_TRY(hipEventRecord(f.ev_aux[0], stream));
+                HIP_TRY(hipStreamWaitEvent(f.aux_stream, f.ev_aux[0], 0));
+                RenderArgs heavy = ra;
+                heavy.tile_order = nullptr;
+                heavy.pixel_list = f.heavy_list;
+                heavy.pixel_list_count = f.heavy_count;
+                heavy.cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
+                heavy.pixels_per_wave = heavy_ppw;
+                if (sphere_list_kernel) heavy.coop_threshold = 65;  // always the grouped scan
+                heavy.grid_blocks = heavy_blocks;
+                heavy.max_blocks_per_cu = 8;
+                heavy.wave_priority = heavy_prio;
+                HIP_TRY(p->variant ? launch_render_fast(ds, heavy, f.aux_stream) : launch_render_strict(ds, heavy, f.aux_stream));
+                HIP_TRY(hipEventRecord(f.ev_aux[1], f.aux_stream));
+                ra.pix_class = f.pix_class;
             }
         }
     }
@@ -533,10 +596,38 @@ int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
     // other film's frame as well and serialise frames that were launched to overlap.
     HIP_TRY(hipMemcpyAsync(f.host_counters, f.ray_counter, kCounterWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(f.ev[3], stream));
+    return RT_OK;
+}
+
+int rt_render_launch(rt_scene *scene, rt_film *film, const rt_render_params *p)
+{
+    if (!scene || !film || !p) return fail(RT_ERR_INVALID, "rt_render_launch: null argument");
+    SceneImpl &s = *S(scene);
+    FilmImpl &f = *F(film);
+    if (p->width != f.width || p->height != f.height || p->stripe_rows != f.stripe_rows || p->rank != f.rank ||
+        p->world_size != f.world_size || p->device != f.device)
+        return fail(RT_ERR_INVALID, "rt_render_launch: params do not match the film's geometry/device");
+    if (p->samples_per_pixel < 0 || p->max_depth < 0) return fail(RT_ERR_INVALID, "rt_render_launch: negative spp/depth");
+    if (p->variant != 0 && p->variant != 1) return fail(RT_ERR_INVALID, "rt_render_launch: variant must be 0 (strict) or 1 (fast)");
+    if (p->pixels_per_wave < 0 || p->pixels_per_wave > 64) return fail(RT_ERR_INVALID, "rt_render_launch: pixels_per_wave must be 0 (automatic) or 1..64");
+    if (f.in_flight)
+        return fail(RT_ERR_STATE, "rt_render_launch: this film already has a render in flight (rt_render_finish it first; "
+                                  "use one film per frame in flight)");
+    if (int rc = rt_scene_upload(scene, f.device)) return rc;
+    if (int rc = select_device(f.device)) return rc;
+    hipStream_t stream = p->stream ? (hipStream_t)p->stream : f.own_stream;
+    // In flight from here on: the scene may not change (or go away) under a kernel that is already on the stream, also
+    // when a later step of the launch fails.
     f.last_stream = stream;
-    f.in_flight = true;
-    f.scene_in_flight = &s;
-    s.launches_in_flight++;
+    mark_in_flight(s, f);
+    const int rc = enqueue_frame(s, f, p, stream);
+    if (rc != RT_OK) {
+        const std::string why = rt_last_error();
+        hipStreamSynchronize(stream);  // whatever did get enqueued
+        mark_done(f);
+        set_error(why);
+        return rc;
+    }
     f.last_samples = (uint64_t)f.n_pixels * (uint64_t)p->samples_per_pixel;
     f.last_variant = p->variant;
     return RT_OK;
@@ -549,19 +640,17 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
     FilmImpl &f = *F(film);
     if (!f.in_flight) return fail(RT_ERR_STATE, "rt_render_finish: nothing launched");
     if (int rc = select_device(f.device)) return rc;
-    HIP_TRY(hipEventSynchronize(f.ev[3]));
-    f.in_flight = false;
-    if (f.scene_in_flight) {
-        f.scene_in_flight->launches_in_flight--;
-        f.scene_in_flight = nullptr;
-    }
+    const hipError_t waited = hipEventSynchronize(f.ev[3]);
+    if (waited != hipSuccess && f.last_stream) hipStreamSynchronize(f.last_stream);  // whatever is left on the stream
+    mark_done(f);  // also when the wait failed: the scene must not stay locked for ever
+    if (waited != hipSuccess) return hip_fail(waited, "hipEventSynchronize(render finished)");
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         float ms_seed = 0, ms_render = 0;
         HIP_TRY(hipEventElapsedTime(&ms_seed, f.ev[0], f.ev[1]));
         HIP_TRY(hipEventElapsedTime(&ms_render, f.ev[1], f.ev[2]));
         const unsigned long long rays = f.host_counters[0];
-        if (std::getenv("RTOW_PRINT_HEAVY") && f.heavy_count && f.pix_cost) {  // diagnostics: the rehearsal's cost classes
+        if (tune_set("RTOW_PRINT_HEAVY") && f.heavy_count && f.pix_cost) {  // diagnostics: the rehearsal's cost classes
             uint32_t n_heavy = 0;
             std::vector<uint32_t> cost(f.n_pixels);
             HIP_TRY(hipMemcpy(&n_heavy, f.heavy_count, sizeof n_heavy, hipMemcpyDeviceToHost));
@@ -576,12 +665,12 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
             for (int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", hist[k]);
             std::fprintf(stderr, "\n");
         }
-        if (std::getenv("RTOW_PRINT_STAMPS")) {  // diagnostic builds (-DRT_STAMP=1): 100 MHz wall-clock ticks
+        if (tune_set("RTOW_PRINT_STAMPS")) {  // diagnostic builds (-DRT_STAMP=1): 100 MHz wall-clock ticks
             const unsigned long long *st = f.host_counters;
             std::fprintf(stderr, "stamps: start %llu  queue exhausted +%.3f ms  first wave out +%.3f ms  last wave out +%.3f ms\n",
                          st[5], (st[2] - st[5]) * 1e-5, (st[4] - st[5]) * 1e-5, (st[3] - st[5]) * 1e-5);
         }
-        if (std::getenv("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
+        if (tune_set("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;
             const char *name[24] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
                                     "    record+xforms", "    box", "    sub-BVH", "    other geometry", "", "", "", "",
@@ -606,6 +695,7 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         stats->kernel_vgprs = (uint32_t)f.last_kernel.vgprs;
         stats->lds_bytes = (uint32_t)f.last_kernel.lds_bytes;
         stats->kernel_kind = (uint32_t)f.last_kernel.kind;
+        stats->pixels_per_wave = (uint32_t)f.last_pixels_per_wave;
     }
     return RT_OK;
 }

@@ -52,9 +52,11 @@ namespace {
 //              768 threads per CU -- three waves per SIMD as before, but one copy of the scene tables in the CU's 160 KB of LDS
 //              instead of three in 52 KB each: besides the node rows, the box rows and the sphere table fit as well
 //   FAST       primitive-only BVH world walked through the library's own SAH tree, near child first (flat_scene.h FastNodeRec)
+//   GROUPED    list scan with the leaves of every ray dealt to several lanes (scan_leaves_grouped): launches with pixels_per_wave < 64
 template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false, bool NESTED_ = false,
-          int BLOCK_ = 256, bool FAST_ = false>
+          int BLOCK_ = 256, bool FAST_ = false, bool GROUPED_ = false>
 struct Traits {
+    static constexpr bool GROUPED = GROUPED_ && WORLD_ == 1 && !MEDIA_ && !NESTED_;
     static constexpr bool FAST = FAST_ && !COMPOSITE_ && WORLD_ == 0;
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool NESTED = NESTED_ && COMPOSITE_;
@@ -1831,6 +1833,96 @@ DEV void scan_grouped(const SphereView &sv, uint32_t lane, unsigned long long to
     }
 }
 
+// ---- lanes-per-ray scan of a list world (R/HittableList.h:39-57) ---------------------------------------------------------
+// A pixel's samples are one sequential chain (one RNG stream), so when a launch has fewer pixels than the device has lanes
+// -- a small frame, one rank's stripes of a frame -- nothing shortens the frame but a shorter chain per ray.  With
+// pixels_per_wave = 64 / g the pixels sit in the wave's first 64 / g lanes and the g lanes of group q share the ray of lane
+// q: lane s of the group tests leaves s, s + g, ... with its own running closest hit, then one reduction per group picks
+// the hit HittableList::Hit returns.  Which one that is when two leaves answer the SAME t depends on the kinds: a sphere
+// is accepted for t < closest only (R/Sphere.h:38,50), a quad -- hence a box face, an instanced box -- for t <= closest
+// (R/Quad.h:59-64 rejects t > tMax only).  Walking the list in order, the first leaf that reaches the final t sets it, a
+// later quad at that t replaces it, a later sphere does not: the winner is the LAST quad among the tied leaves if there is
+// one, else the FIRST sphere.  `key` orders exactly that (quads above spheres, later quads and earlier spheres higher),
+// and every lane's own sub-sequence obeys the same rule by running the reference's tests in order.  A leaf's answer under
+// a looser bound than the list would have given it is the same answer or one that loses the reduction (no leaf draws
+// random numbers in these kernels: T::MEDIA is false), so the frame is the sequential scan's bit for bit.
+template <int CTRL, int ROW_MASK>
+DEV void tie_step(double &t, uint32_t &key)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(t), __double2loint(t), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(t), __double2hiint(t), CTRL, ROW_MASK, 0xf, false);
+    uint32_t ok = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, CTRL, ROW_MASK, 0xf, false);
+    double ot = __hiloint2double(hi, lo);
+    bool take = (ot < t) || (ot == t && ok > key);
+    t = take ? ot : t;
+    key = take ? ok : key;
+}
+DEV void tie_with_lane(double &t, uint32_t &key, int partner)
+{
+    double ot = lane_read(t, partner);
+    uint32_t ok = (uint32_t)lane_read((int)key, partner);
+    bool take = (ot < t) || (ot == t && ok > key);
+    t = take ? ot : t;
+    key = take ? ok : key;
+}
+
+template <class T>
+DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG);
+
+template <class T>
+DEV void scan_leaves_grouped(const DeviceScene &sc, uint32_t lane, int log2g, unsigned long long todo, const Ray &ray, double tmin, double tmax,
+                             HitInfo &best, bool &hit, Xorwow &rng PH_ARG)
+{
+    const uint32_t g = 1u << log2g;
+    const uint32_t q = lane >> log2g, s = lane & (g - 1u);  // group q serves the pixel of lane q; my place in the group
+    Ray r;
+    r.o = mk(lane_read(ray.o.x, (int)q), lane_read(ray.o.y, (int)q), lane_read(ray.o.z, (int)q));
+    r.d = mk(lane_read(ray.d.x, (int)q), lane_read(ray.d.y, (int)q), lane_read(ray.d.z, (int)q));
+    r.tm = lane_read(ray.tm, (int)q);
+    const bool wanted = ((todo >> q) & 1ull) != 0;
+    const double a = dot(r.d, r.d);
+    const uint32_t n = sc.n_world_items;
+    HitInfo mine;
+    mine.t = 0.0;
+    mine.ref = kNone;
+    mine.obj = kNone;
+    double closest = tmax;
+    uint32_t k_best = 0;
+    bool any = false;
+    if (wanted) {
+        for (uint32_t k = s; k < n; k += g) {
+            const uint32_t ref = ((const RT_CONST uint32_t *)(uintptr_t)sc.world_items)[k];
+            if (leaf_test<T>(sc, ref, r, a, tmin, closest, mine, rng PH_PASS)) {
+                any = true;
+                closest = mine.t;
+                k_best = k;
+            }
+        }
+    }
+    double wt = any ? closest : __builtin_inf();
+    const uint32_t my_key = !any ? 0u : ((mine.ref >> kRefShift) == REF_QUAD ? (0x80000000u | k_best) : (0x7FFFFFFFu - k_best));
+    uint32_t wkey = my_key;
+    if (log2g >= 1) tie_step<0xB1, 0xf>(wt, wkey);   // quad_perm [1,0,3,2]
+    if (log2g >= 2) tie_step<0x4E, 0xf>(wt, wkey);   // quad_perm [2,3,0,1]
+    if (log2g >= 3) tie_step<0x141, 0xf>(wt, wkey);  // row_half_mirror
+    if (log2g >= 4) tie_step<0x140, 0xf>(wt, wkey);  // row_mirror
+    if (log2g >= 5) tie_with_lane(wt, wkey, (int)lane ^ 16);
+    if (log2g >= 6) tie_with_lane(wt, wkey, (int)lane ^ 32);
+    // every lane of a group now holds the group's (t, key); the lane whose own answer that is hands its record to the pixel's lane
+    const unsigned long long holders = __ballot(any && my_key == wkey);
+    const unsigned long long group_bits = log2g >= 6 ? holders : ((holders >> (lane << log2g)) & ((1ull << g) - 1ull));  // as owner: group `lane`
+    const int src = (int)(lane << log2g) + (group_bits ? __ffsll((long long)group_bits) - 1 : 0);
+    const double rt = lane_read(wt, src & 63);
+    const uint32_t rref = (uint32_t)lane_read((int)mine.ref, src & 63);
+    const uint32_t robj = (uint32_t)lane_read((int)mine.obj, src & 63);
+    if (lane < (64u >> log2g) && ((todo >> lane) & 1ull)) {
+        hit = group_bits != 0;
+        best.t = rt;
+        best.ref = rref;
+        best.obj = robj;
+    }
+}
+
 // The same grouped scan for a BVH world of spheres / unit-time moving spheres (config C3), for thin waves once the pixel
 // queue has run dry.  A pixel's samples are one sequential chain, so a frame ends with a few long pixels (glass: up to
 // max_depth rays per sample); walked, each of their rays costs ~36 dependent node visits with most of the wave idle.
@@ -2679,13 +2771,18 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #if RT_PHASES
         const unsigned long long ph_ts = __builtin_readcyclecounter();
 #endif
+        if constexpr (T::GROUPED) {  // every ray's leaves are dealt to 64 / pixels_per_wave lanes (the launcher keeps pixels_per_wave a power of two below 64)
+            PH_BEGIN();
+            scan_leaves_grouped<T>(sc, lane, 6 - (__ffs(a.pixels_per_wave) - 1), todo, ray, 0.001, DBL_MAX, h, hit, rng PH_PASS);
+            PH_END(1, (todo >> lane) & 1ull);
+        }
         if ((todo >> lane) & 1ull) {
             const bool no_bounces = a.max_depth <= 0;  // R/kernel.cu:71: the bounce loop never runs, RayColor returns black
             if (!no_bounces) {
                 nrays++;
                 pix_rays++;
             }
-            if constexpr (T::WORLD == 1) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng PH_PASS);
+            if constexpr (T::WORLD == 1 && !T::GROUPED) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng PH_PASS);
             bool path_ends;
             if (no_bounces) {
                 path_ends = true;
@@ -2942,6 +3039,13 @@ using TListPrims = Traits<1, false, false, 4>;  // 127-129 VGPRs without the bou
 #define RT_WAVES_LIST_INSTANCES 4  // 128 VGPRs and 52 B of scratch for a fourth wave per SIMD: C4 +2.4 % (139 VGPRs, none, three waves before)
 #endif
 using TListInstances = Traits<1, true, false, RT_WAVES_LIST_INSTANCES, false>;
+// The same two with the leaves of every ray dealt to lanes (pixels_per_wave < 64: fewer pixels than lanes, the frame is bound
+// by the latency of a ray, not by throughput -- registers matter more than a fourth wave)
+#ifndef RT_WAVES_GROUPED
+#define RT_WAVES_GROUPED 3
+#endif
+using TListPrimsGrouped = Traits<1, false, false, RT_WAVES_GROUPED, false, false, false, 256, false, true>;
+using TListInstancesGrouped = Traits<1, true, false, RT_WAVES_GROUPED, false, false, false, 256, false, true>;
 
 // Do the node rows and the sphere / material rows of a primitive world fit the library-tree kernel's LDS?  (The same sums as
 // launch_one<TBvhPrimsFast>'s placement, for callers that have no reference tree to fall back to.)
@@ -3057,7 +3161,8 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
         if (e != hipSuccess) return e;
         info->vgprs = attr.numRegs;
         info->lds_bytes = (int)(attr.sharedSizeBytes + lds);
-        info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0) + (T::NESTED ? 32 : 0) + (T::FAST ? 64 : 0);
+        info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0) + (T::NESTED ? 32 : 0) + (T::FAST ? 64 : 0) +
+                     (T::GROUPED ? 128 : 0);
         return hipSuccess;
     }
     if (a.n_pixels == 0 || a.spp <= 0) return hipSuccess;
@@ -3089,7 +3194,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
 
 // instantiations of group 1, by id (defined in the RT_GROUP == 1 translation unit)
 enum CompositeKernel { CK_LIST_PRIMS, CK_LIST_INSTANCES, CK_LIST_GENERAL, CK_LIST_NESTED, CK_BVH_INSTANCES, CK_BVH_MEDIA,
-                       CK_BVH_GENERAL, CK_BVH_GENERAL_DEEP, CK_BVH_NESTED };
+                       CK_BVH_GENERAL, CK_BVH_GENERAL_DEEP, CK_BVH_NESTED, CK_LIST_PRIMS_GROUPED, CK_LIST_INSTANCES_GROUPED };
 hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info);
 
 #if RT_GROUP == 1
@@ -3098,6 +3203,8 @@ hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc
     switch (which) {
     case CK_LIST_PRIMS: return launch_one<TListPrims>(sc, a, stream, info);
     case CK_LIST_INSTANCES: return launch_one<TListInstances>(sc, a, stream, info);
+    case CK_LIST_PRIMS_GROUPED: return launch_one<TListPrimsGrouped>(sc, a, stream, info);
+    case CK_LIST_INSTANCES_GROUPED: return launch_one<TListInstancesGrouped>(sc, a, stream, info);
     case CK_LIST_GENERAL: return launch_one<TListGeneral>(sc, a, stream, info);
     case CK_LIST_NESTED: return launch_one<TListNested>(sc, a, stream, info);
     case CK_BVH_INSTANCES: return launch_one<TBvhInstances>(sc, a, stream, info);
@@ -3123,7 +3230,12 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
     if (sc.flags & SCENE_HAS_TREES) return composite_kernel(sc.world_kind == WORLD_BVH ? CK_BVH_NESTED : CK_LIST_NESTED);
     const bool media = (sc.flags & SCENE_HAS_MEDIA) != 0;
     const bool scan_world = sc.world_kind == WORLD_LIST || (sc.n_world_items <= 16u && sc.scan_cost <= (uint32_t)a.small_world && !a.always_walk);
-    if (scan_world && !rich && !media && !a.force_general) return composite_kernel(composite ? CK_LIST_INSTANCES : CK_LIST_PRIMS);
+    if (scan_world && !rich && !media && !a.force_general) {
+        // pixels_per_wave < 64 (a power of two: rt_render_launch): the instantiation that deals a ray's leaves to lanes
+        const bool grouped = a.pixels_per_wave < 64 && (a.pixels_per_wave & (a.pixels_per_wave - 1)) == 0 && a.pixels_per_wave > 0;
+        if (grouped) return composite_kernel(composite ? CK_LIST_INSTANCES_GROUPED : CK_LIST_PRIMS_GROUPED);
+        return composite_kernel(composite ? CK_LIST_INSTANCES : CK_LIST_PRIMS);
+    }
     if (sc.world_kind == WORLD_BVH) {
         if (!composite && !rich && !a.force_general)
             return (sc.fast_nodes && !a.reference_tree && sc.n_fast_nodes * kFastNodeBytes <= kFastLdsBudget)

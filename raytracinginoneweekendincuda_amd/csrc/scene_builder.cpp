@@ -243,6 +243,52 @@ static int build_tree(SceneImpl *s, HostHittable &bvh, std::vector<uint32_t> &ob
 // flattening
 // ------------------------------------------------------------------------------------------------
 namespace {
+// Coincident primitives: two identical spheres, or two quads in one plane whose rectangles overlap.  A ray that hits both
+// gets the same t twice, and then the ORDER of the tests decides which material it sees: the reference's list keeps the
+// first sphere it meets (strict `<`, R/Sphere.h:38,50) and the last quad (inclusive interval, R/Quad.h:59-64).  The
+// library's own accelerators (the near-child-first tree of a primitive world, the sub-BVH / cooperative scan of a large
+// group) meet the primitives in another order, so they are not built over such a set: it keeps the reference's tree or
+// its linear list.  Exact comparisons on purpose: surfaces that differ in the last bit do not tie.
+static bool has_coincident_primitives(const SceneImpl &s, const std::vector<uint32_t> &handles)
+{
+    struct Key {
+        double v[10];
+        uint32_t handle;
+    };
+    auto less = [](const Key &a, const Key &b) { return std::lexicographical_compare(a.v, a.v + 10, b.v, b.v + 10); };
+    auto same = [](const Key &a, const Key &b) { return std::equal(a.v, a.v + 10, b.v); };
+    std::vector<Key> spheres, planes;
+    for (uint32_t hnd : handles) {
+        const HostHittable &h = s.hittables[hnd - 1];
+        if (h.kind == HKind::Sphere || h.kind == HKind::MovingSphere) {
+            const bool moving = h.kind == HKind::MovingSphere;
+            spheres.push_back({{h.c0.x, h.c0.y, h.c0.z, moving ? h.c1.x : h.c0.x, moving ? h.c1.y : h.c0.y, moving ? h.c1.z : h.c0.z,
+                                moving ? h.t0 : 0.0, moving ? h.t1 : 0.0, h.radius, moving ? 1.0 : 0.0}, hnd});
+        } else if (h.kind == HKind::Quad) {
+            // the plane, with the sign of the normal fixed by its first non-zero component
+            double n[3] = {h.normal.x, h.normal.y, h.normal.z}, d = h.plane_d;
+            const double lead = n[0] != 0.0 ? n[0] : (n[1] != 0.0 ? n[1] : n[2]);
+            if (lead < 0.0) {
+                for (double &c : n) c = -c;
+                d = -d;
+            }
+            planes.push_back({{n[0] + 0.0, n[1] + 0.0, n[2] + 0.0, d + 0.0, 0, 0, 0, 0, 0, 0}, hnd});  // + 0.0: -0.0 -> +0.0
+        }
+    }
+    std::sort(spheres.begin(), spheres.end(), less);
+    for (size_t k = 1; k < spheres.size(); k++)
+        if (same(spheres[k - 1], spheres[k])) return true;
+    std::sort(planes.begin(), planes.end(), less);
+    for (size_t a = 0; a < planes.size(); a++)
+        for (size_t b = a + 1; b < planes.size() && same(planes[a], planes[b]); b++) {
+            const Box &x = s.hittables[planes[a].handle - 1].box, &y = s.hittables[planes[b].handle - 1].box;
+            bool overlap = true;
+            for (int k = 0; k < 3; k++) overlap &= x.lo[k] <= y.hi[k] && y.lo[k] <= x.hi[k];
+            if (overlap) return true;
+        }
+    return false;
+}
+
 struct Flattener {
     SceneImpl &s;
     FlatScene &f;
@@ -259,7 +305,7 @@ struct Flattener {
     // zero displacement (centre(t) = c0 + frac * 0 = c0 exactly), so that a wave's leaf tests run one code path
     // instead of two.  Not done if a centre component is -0.0 (c0 + 0.0 would flip it to +0.0).
     bool unify_spheres = false;
-    const bool plain_quads = std::getenv("RTOW_PLAIN_QUADS") != nullptr && std::atoi(std::getenv("RTOW_PLAIN_QUADS")) != 0;
+    const bool plain_quads = (s.options & RT_SCENE_PLAIN_QUADS) != 0;
 
     uint32_t add_primitive(const HostHittable &h, bool world_leaf = false)
     {
@@ -281,7 +327,7 @@ struct Flattener {
         }
         f.quads.push_back({h.q.x, h.q.y, h.q.z, h.u.x, h.u.y, h.u.z, h.v.x, h.v.y, h.v.z, h.w.x, h.w.y, h.w.z,
                            h.normal.x, h.normal.y, h.normal.z, h.plane_d});
-        // RTOW_PLAIN_QUADS=1 (tests): every quad takes the general test, boxes stay lists of six quads
+        // RT_SCENE_PLAIN_QUADS (tests): every quad takes the general test, boxes stay lists of six quads
         f.quad_aa.push_back(plain_quads ? AAQuad{} : axis_aligned(f.quads.back()));
         f.quad_mat.push_back(h.material - 1);
         return make_ref(REF_QUAD, (uint32_t)f.quads.size() - 1);
@@ -558,7 +604,7 @@ struct Flattener {
                 all_q &= k == HKind::Quad;
             }
             obj.count = (uint32_t)prims.size();
-            if (prims.size() >= kSubBvhMinPrims) {
+            if (prims.size() >= kSubBvhMinPrims && !has_coincident_primitives(s, prims)) {
                 // A closest-hit scan and a BVH over the same primitives return the same hit (the reference's own
                 // invariant, Docs 2-3 BVH :733,:772); primitives draw no random numbers, so nothing else changes.
                 HostHittable sub{};
@@ -820,9 +866,10 @@ struct FastBuilder {
 };
 } // namespace
 
-static void build_fast_tree(FlatScene &f)
+static void build_fast_tree(FlatScene &f, bool reference_tree_only)
 {
     f.fast_nodes.clear();
+    if (reference_tree_only) return;  // RT_SCENE_REFERENCE_TREE_ONLY, or leaves that coincide (has_coincident_primitives)
     const size_t n = f.world_items.size();
     // (built for list worlds of primitives as well: RT_FLAG_ACCELERATE_LISTS renders them through it)
     if (n < 3 || n > 40000 || !f.objects.empty() || !f.boxes.empty() || !f.tree_nodes.empty()) return;
@@ -830,8 +877,6 @@ static void build_fast_tree(FlatScene &f)
         const uint32_t tag = ref >> kRefShift;
         if (tag != REF_SPHERE && tag != REF_MSPHERE && tag != REF_QUAD) return;
     }
-    if (const char *e = std::getenv("RTOW_REFERENCE_TREE"))  // A/B experiments: keep the reference's tree only
-        if (std::atoi(e) != 0) return;
     FastBuilder fb{f.leaf_boxes, f.world_items, {}};
     std::vector<uint32_t> idx(n);
     for (size_t k = 0; k < n; k++) idx[k] = (uint32_t)k;
@@ -953,7 +998,7 @@ int flatten_scene(SceneImpl &s)
         }
         f.scan_cost = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
     }
-    build_fast_tree(f);
+    build_fast_tree(f, (s.options & RT_SCENE_REFERENCE_TREE_ONLY) != 0 || has_coincident_primitives(s, leaves));
     {
         // Rows of the list scan's conservative filter (render.hip filter_four): centre and |c|^2 - r^2, and the
         // scene's reach max(|c| + r) that bounds the filter's rounding error.  A non-finite row becomes (0, 0, 0, -inf):
@@ -1017,6 +1062,7 @@ int flatten_scene(SceneImpl &s)
 
 SceneImpl::~SceneImpl()
 {
+    if (launches_in_flight > 0 || !films_in_flight.empty()) wait_for_films_in_flight(*this);  // kernels still read the tables
     for (DeviceTables *t : device)
         if (t) release_device_tables(t);
 }
@@ -1053,6 +1099,14 @@ void rt_rng_state(const rt_rng *rng, uint32_t out6[6])
 }
 
 rt_scene *rt_scene_create(void) { return reinterpret_cast<rt_scene *>(new SceneImpl); }
+int rt_scene_set_options(rt_scene *scene, uint32_t options)
+{
+    if (!scene) return fail(RT_ERR_INVALID, "rt_scene_set_options: null scene");
+    if (options & ~(uint32_t)(RT_SCENE_PLAIN_QUADS | RT_SCENE_REFERENCE_TREE_ONLY)) return fail(RT_ERR_INVALID, "rt_scene_set_options: unknown option bit");
+    S(scene)->options = options;
+    S(scene)->committed = false;  // takes effect with the next rt_scene_commit
+    return RT_OK;
+}
 void rt_scene_destroy(rt_scene *scene) { delete S(scene); }
 
 // ---- textures ----

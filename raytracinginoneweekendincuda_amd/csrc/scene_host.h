@@ -113,6 +113,8 @@ struct SceneImpl {
     // scene may not be changed while a kernel may still be reading its tables.
     uint64_t generation = 0;
     int launches_in_flight = 0;
+    std::vector<void *> films_in_flight;  // the FilmImpl of every launch counted above (device_scene.cpp)
+    uint32_t options = 0;                 // RT_SCENE_* (rt_scene_set_options), read by the next rt_scene_commit
 
     ~SceneImpl();
 };
@@ -133,5 +135,8 @@ int flatten_scene(SceneImpl &s);
 
 // device side (device_scene.cpp)
 void release_device_tables(DeviceTables *t);
+// A scene that goes away while launches are in flight: wait for each of them and make their films forget the scene
+// (rt_scene_destroy; the films stay valid, their rt_render_finish then only reports).
+void wait_for_films_in_flight(SceneImpl &s);
 
 } // namespace rtow

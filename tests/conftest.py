@@ -261,6 +261,26 @@ def oracle():
     return Oracle()
 
 
+@pytest.fixture(autouse=True, scope="session")
+def one_lane_per_ray_unless_asked():
+    """rt_render_params.pixels_per_wave = 0 lets the library give every ray several lanes when a launch has fewer pixels than
+    the device has lanes -- which is every frame of a few thousand pixels these tests render.  The tests of the individual
+    kernels mean the one-lane-per-ray instantiations, so inside the test session the wrappers' default is 64; the tests of the
+    lanes-per-ray scans pass pixels_per_wave themselves (0 = the library's own choice)."""
+    import raytracinginoneweekendincuda_amd as rt
+    orig_render, orig_params = rt.Scene.render, rt.Film.params
+
+    def render(self, *a, pixels_per_wave=64, **kw):
+        return orig_render(self, *a, pixels_per_wave=pixels_per_wave, **kw)
+
+    def params(self, *a, pixels_per_wave=64, **kw):
+        return orig_params(self, *a, pixels_per_wave=pixels_per_wave, **kw)
+
+    rt.Scene.render, rt.Film.params = render, params
+    yield
+    rt.Scene.render, rt.Film.params = orig_render, orig_params
+
+
 def synthetic_earth(seed=1984, w=256, h=128):
     """Procedural stand-in for earthmap.jpg (the asset cannot travel): smooth bands + noise."""
     rng = np.random.default_rng(seed)

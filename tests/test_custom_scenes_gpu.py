@@ -117,6 +117,113 @@ def test_quad_zoo_matches_the_oracle(world_kind):
     check(_quad_zoo(world_kind), w=96, h=64, spp=8)
 
 
+# ---- lanes-per-ray scan of list worlds (rt_render_params.pixels_per_wave, render.hip scan_leaves_grouped) ----
+def _cornell(world_kind):
+    """The Cornell box with its two instanced boxes (R/kernel.cu:363-398, config C4) through the shared constructor names."""
+    def build(s, Rng):
+        red, white, green = s.Lambertian((0.65, 0.05, 0.05)), s.Lambertian((0.73, 0.73, 0.73)), s.Lambertian((0.12, 0.45, 0.15))
+        light = s.DiffuseLight((15.0, 15.0, 15.0))
+        items = [s.Quad((555, 0, 0), (0, 555, 0), (0, 0, 555), green), s.Quad((0, 0, 0), (0, 555, 0), (0, 0, 555), red),
+                 s.Quad((343, 554, 332), (-130, 0, 0), (0, 0, -105), light), s.Quad((0, 0, 0), (555, 0, 0), (0, 0, 555), white),
+                 s.Quad((555, 555, 555), (-555, 0, 0), (0, 0, -555), white), s.Quad((0, 0, 555), (555, 0, 0), (0, 555, 0), white),
+                 s.Translate(s.RotateY(s.MakeBox((0, 0, 0), (165, 330, 165), white), 15.0), (265, 0, 295)),
+                 s.Translate(s.RotateY(s.MakeBox((0, 0, 0), (165, 165, 165), white), -18.0), (130, 0, 65))]
+        s.SetWorld(s.BvhNode(items) if world_kind == 0 else s.HittableList(items))
+        s.Camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0, (0, 0, 0))
+        s.Commit()
+    return build
+
+
+def _spheres_and_quads(world_kind):
+    """A list of 13 primitives (the list-of-primitives kernel): more leaves than lanes per ray at most group widths."""
+    def build(s, Rng):
+        items = [s.Sphere((0, -1000, 0), 1000.0, s.Lambertian((0.5, 0.5, 0.5)))]
+        for k in range(9):
+            mat = (s.Lambertian((0.2 + 0.08 * k, 0.3, 0.7 - 0.06 * k)), s.Metal((0.8, 0.7, 0.5), 0.05 * k), s.Dielectric(1.5))[k % 3]
+            items.append(s.Sphere((-4.0 + k, 0.45 + 0.05 * k, -1.0 + 0.7 * (k % 4)), 0.45 + 0.05 * k, mat))
+        items.append(s.Quad((-5, 0, -4), (10, 0, 0), (0, 4, 0), s.Metal((0.9, 0.9, 0.9), 0.0)))
+        items.append(s.Quad((-5, 0, -4), (0, 0, 8), (0, 3, 0), s.Lambertian((0.8, 0.2, 0.2))))
+        items.append(s.MovingSphere((2, 2, 0), (2, 2.4, 0), 0.0, 1.0, 0.4, s.Lambertian((0.1, 0.8, 0.2))))
+        s.SetWorld(s.BvhNode(items) if world_kind == 0 else s.HittableList(items))
+        s.Camera((1, 2.5, 9), (0, 0.8, 0), (0, 1, 0), 40.0, W / H, 0.05, 9.0, 0.0, 1.0)
+        s.Commit()
+    return build
+
+
+@pytest.mark.parametrize("name,world_kind", [("cornell", 0), ("cornell", 1), ("zoo", 1), ("prims", 0), ("prims", 1)])
+def test_lanes_per_ray_list_scan_gives_the_one_lane_per_ray_frame(name, world_kind):
+    """pixels_per_wave < 64: the leaves of every ray are dealt to 64 / pixels_per_wave lanes and one reduction per group picks
+    the hit -- the same frame, ray count and (checked against the oracle once) RNG streams as the sequential scan, for every
+    group width, in both builds.  Cornell as a BvhNode world is a small world rendered by the list kernels in leaf order."""
+    build = {"cornell": _cornell, "zoo": _quad_zoo, "prims": _spheres_and_quads}[name](world_kind)
+    prod, orc = build_both(build)
+    w, h, spp = 48, 32, 6
+    want = orc.render(w, h, spp)
+    for variant in (0, 1):
+        ref, st0 = prod.render(w, h, spp, variant=variant, pixels_per_wave=64)
+        assert st0.kernel_kind in (8, 10) and st0.pixels_per_wave == 64
+        if variant == 0:
+            exact, within, _ = compare(ref, want)
+            assert within >= 0.999 and exact >= 0.99
+        for ppw in (32, 16, 8, 4, 2, 1):
+            got, st = prod.render(w, h, spp, variant=variant, pixels_per_wave=ppw)
+            assert st.kernel_kind == st0.kernel_kind + 128 and st.pixels_per_wave == ppw, (st.kernel_kind, st.pixels_per_wave)
+            assert st.rays == st0.rays, (ppw, st.rays, st0.rays)
+            assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), (name, variant, ppw)
+
+
+def test_pixels_per_wave_is_chosen_from_the_pixels_a_film_owns():
+    """pixels_per_wave = 0: a frame with fewer pixels than the device has lanes gives every ray several lanes (the chain of a
+    pixel's rays is what bounds such a frame), a frame with pixels enough for every lane keeps one lane per ray."""
+    prod, _ = build_both(_cornell(0))
+    small, st_small = prod.render(64, 64, 4, variant=0, pixels_per_wave=0)                  # 4096 pixels
+    assert st_small.pixels_per_wave < 64 and st_small.kernel_kind == 10 + 128
+    ref, st_ref = prod.render(64, 64, 4, variant=0, pixels_per_wave=64)
+    assert np.array_equal(small.view(np.uint64), ref.view(np.uint64)) and st_small.rays == st_ref.rays
+    _, st_big = prod.render(1024, 1024, 1, variant=0, pixels_per_wave=0)                    # a million pixels
+    assert st_big.pixels_per_wave == 64 and st_big.kernel_kind == 10
+
+
+# ---- coincident primitives: the order of the tests decides ----
+def _coincident(world_kind):
+    def build(s, Rng):
+        red, green, blue, white = (s.Lambertian((0.8, 0.1, 0.1)), s.Lambertian((0.1, 0.8, 0.1)), s.Lambertian((0.1, 0.1, 0.8)),
+                                   s.Lambertian((0.8, 0.8, 0.8)))
+        mirror = s.Metal((0.9, 0.9, 0.9), 0.0)
+        items = [s.Sphere((-1.2, 0.5, 0), 0.5, red), s.Sphere((-1.2, 0.5, 0), 0.5, green),             # the same sphere twice: first one wins
+                 s.Quad((0.2, 0, -0.5), (1.2, 0, 0), (0, 1.2, 0), blue), s.Quad((0.6, 0.3, -0.5), (1.2, 0, 0), (0, 1.2, 0), red),  # one plane: the later one wins where they overlap
+                 s.MakeBox((2.2, 0, -1), (3.0, 0.8, -0.2), green), s.Quad((2.0, 0.2, -0.2), (1.2, 0, 0), (0, 0.4, 0), mirror),   # a quad in the plane of a box face
+                 s.Quad((-6, 0, -6), (12, 0, 0), (0, 0, 12), white)]
+        for k in range(12):   # enough leaves for a BvhNode world to be walked rather than scanned
+            items.append(s.Sphere((-5.0 + 0.9 * k, 0.2, 2.0), 0.2, (red, green, blue)[k % 3]))
+        s.SetWorld(s.BvhNode(items) if world_kind == 0 else s.HittableList(items))
+        s.Camera((0.5, 1.5, 6), (0.5, 0.5, 0), (0, 1, 0), 45.0, W / H, 0.0, 10.0)
+        s.Commit()
+    return build
+
+
+@pytest.mark.parametrize("world_kind", [0, 1])
+def test_coincident_primitives_resolve_like_the_reference(world_kind):
+    """Two identical spheres, two overlapping quads in one plane, a quad in the plane of a box face: a ray gets the same t
+    from both and the ORDER of the tests decides (first sphere: R/Sphere.h:38,50 strict; last quad: R/Quad.h:59-64
+    inclusive).  Such a world gets no library tree (its near-child-first order is not the reference's) -- it is walked /
+    scanned in the reference's order and must equal the oracle; the lanes-per-ray scan resolves ties the same way."""
+    prod, orc = build_both(_coincident(world_kind))
+    assert prod.dump_fast_nodes()[0].shape[0] == 0, "a world with coincident primitives must not get a library tree"
+    want, stats = orc.render(W, H, 8, want_stats=True)
+    got, st = prod.render(W, H, 8, variant=0)
+    exact, within, worst = compare(got, want)
+    print(f"coincident world {world_kind}: kernel kind {st.kernel_kind}, bit-exact {exact:.4f}, within {within:.4f}")
+    assert st.rays == stats["rays"] and within >= 0.999 and exact >= 0.99
+    accel, _ = prod.render(W, H, 8, variant=0, flags=512)   # RT_FLAG_ACCELERATE_LISTS has no tree to use
+    assert np.array_equal(accel.view(np.uint64), got.view(np.uint64))
+    if world_kind == 1:
+        for ppw in (16, 4, 1):
+            grouped, stg = prod.render(W, H, 8, variant=0, pixels_per_wave=ppw)
+            assert stg.kernel_kind & 128 and stg.rays == st.rays
+            assert np.array_equal(grouped.view(np.uint64), got.view(np.uint64)), ppw
+
+
 # ---- general nesting (R/Instance.h, R/ConstantMedium.h, R/HittableList.h, R/BvhNode.h take any Hittable*) ----
 def _room(s, items, cam_from=(0, 1.2, 6.5), cam_at=(0, 0.6, 0), vfov=50.0, bg=(0.55, 0.65, 0.9), world="bvh"):
     floor = s.Quad((-30, -1, -30), (60, 0, 0), (0, 0, 60), s.Lambertian(s.CheckerTexture(0.8, s.SolidColor((0.2, 0.3, 0.1)),

@@ -189,3 +189,48 @@ def test_custom_scene_constructors_match_the_oracles(oracle):
     ob, oorder = build(OracleScene())
     assert np.array_equal(pb.view(np.uint64), ob.view(np.uint64))
     assert porder == oorder and porder != list(range(7))
+
+
+def _sphere_world(extra):
+    s = rt.Scene()
+    grey, red = s.Lambertian((0.7, 0.7, 0.7)), s.Lambertian((0.8, 0.1, 0.1))
+    items = [s.Sphere((0.9 * k, 0.0, -0.3 * k), 0.4, grey) for k in range(6)]
+    items += extra(s, grey, red)
+    s.SetWorld(s.BvhNode(items))
+    s.Camera((0, 1, 8), (0, 0, 0), (0, 1, 0), 40.0, 2.0, 0.0, 10.0)
+    return s
+
+
+def test_worlds_with_coincident_primitives_get_no_library_tree():
+    """The library's near-child-first tree meets the primitives in another order than the reference's tree / list, which
+    decides what a ray sees where two surfaces answer the same t (identical spheres: the first, R/Sphere.h:38,50; overlapping
+    quads in one plane: the last, R/Quad.h:59-64).  Such worlds keep the reference's tree only (no GPU needed to check)."""
+    plain = _sphere_world(lambda s, g, r: [s.Quad((-2, -0.4, -2), (8, 0, 0), (0, 0, 4), g)])
+    plain.Commit()
+    assert plain.dump_fast_nodes()[0].shape[0] > 0
+    twin = _sphere_world(lambda s, g, r: [s.Sphere((0.9, 0.0, -0.3), 0.4, r)])   # the sphere k = 1 once more, another material
+    twin.Commit()
+    assert twin.dump_fast_nodes()[0].shape[0] == 0
+    coplanar = _sphere_world(lambda s, g, r: [s.Quad((-2, -0.4, -2), (8, 0, 0), (0, 0, 4), g), s.Quad((0, -0.4, -1), (1, 0, 0), (0, 0, 1), r)])
+    coplanar.Commit()
+    assert coplanar.dump_fast_nodes()[0].shape[0] == 0
+    apart = _sphere_world(lambda s, g, r: [s.Quad((-2, -0.4, -2), (1, 0, 0), (0, 0, 1), g), s.Quad((3, -0.4, 1), (1, 0, 0), (0, 0, 1), r)])
+    apart.Commit()   # one plane, rectangles that do not touch: no ray meets both
+    assert apart.dump_fast_nodes()[0].shape[0] > 0
+
+
+def test_scene_options_are_read_at_commit():
+    s = _sphere_world(lambda s, g, r: [])
+    s.Commit()
+    n = s.dump_fast_nodes()[0].shape[0]
+    assert n > 0
+    s.set_options(rt.SCENE_REFERENCE_TREE_ONLY)
+    with pytest.raises(rt.RtowError):
+        s.dump_fast_nodes()            # options changed: the scene wants a commit again
+    s.Commit()
+    assert s.dump_fast_nodes()[0].shape[0] == 0
+    s.set_options(0)
+    s.Commit()
+    assert s.dump_fast_nodes()[0].shape[0] == n
+    with pytest.raises(rt.RtowError):
+        s.set_options(1 << 20)

@@ -144,10 +144,9 @@ def test_tile_ranking_does_not_change_the_image(scene_id, earth):
 
 def _quad_zoo(world_kind, plain):
     """Quads in every axis pairing and winding, a slanted quad, boxes plain / instanced / paper-thin / far from the origin."""
-    import os
-    os.environ["RTOW_PLAIN_QUADS"] = "1" if plain else "0"
-    try:
+    if True:
         s = rt.Scene()
+        s.set_options(rt.SCENE_PLAIN_QUADS if plain else 0)
         red, green, grey = s.Lambertian((0.65, 0.05, 0.05)), s.Lambertian((0.12, 0.45, 0.15)), s.Lambertian((0.73, 0.73, 0.73))
         metal, glass, light = s.Metal((0.8, 0.8, 0.9), 0.1), s.Dielectric(1.5), s.DiffuseLight((4.0, 4.0, 4.0))
         items = []
@@ -177,8 +176,6 @@ def _quad_zoo(world_kind, plain):
         s.Camera((0.5, 1.0, 9.0), (0.0, 0.0, -2.0), (0, 1, 0), 55.0, 96 / 64, 0.0, 10.0, 0.0, 1.0, (0.1, 0.1, 0.15))
         s.Commit()
         return s
-    finally:
-        os.environ.pop("RTOW_PLAIN_QUADS", None)
 
 
 @pytest.mark.parametrize("world_kind", [0, 1])
@@ -186,7 +183,7 @@ def _quad_zoo(world_kind, plain):
 def test_axis_aligned_quads_and_boxes_equal_the_general_quad_test(world_kind, variant):
     """flat_scene.h AAQuad / BoxRec: the one-multiply plane and interior tests, the six-planes-at-once box test and its
     inside / outside classification of the hit point give the same frame, bit for bit, as R/Quad.h:52-99 evaluated in
-    full for every quad (RTOW_PLAIN_QUADS=1 at commit time).  Both builds: the shortcut drops exact zeros only."""
+    full for every quad (RT_SCENE_PLAIN_QUADS at commit time).  Both builds: the shortcut drops exact zeros only."""
     fast = _quad_zoo(world_kind, plain=False)
     full = _quad_zoo(world_kind, plain=True)
     assert fast.info()["n_quads"] == full.info()["n_quads"]
@@ -272,17 +269,16 @@ def _many_spheres(n):
 
 
 @pytest.mark.parametrize("n_spheres", [64, 1700])
-def test_cooperative_scans_on_other_list_sizes(n_spheres, monkeypatch):
+def test_cooperative_scans_on_other_list_sizes(n_spheres):
     """64 spheres: one 64-row plane, every group width of the grouped scan sees a ragged tail of the table.
     1700 spheres: the sphere planes no longer fit the LDS budget, so thin waves fall back to the one-ray-at-a-time
-    cooperative scan over the global table.  RTOW_COOP_SINGLE=1 forces that older scan on the LDS planes too."""
+    cooperative scan over the global table.  RT_FLAG_COOP_SINGLE forces that older scan on the LDS planes too."""
     s = _many_spheres(n_spheres)
     ref, st0 = s.render(W, H, SPP, variant=0, coop_threshold=1, overdue=-1)
     assert st0.kernel_kind == 16
     coop, st1 = s.render(W, H, SPP, variant=0, coop_threshold=65, overdue=-1)
     assert np.array_equal(ref.view(np.uint64), coop.view(np.uint64)) and st0.rays == st1.rays
-    monkeypatch.setenv("RTOW_COOP_SINGLE", "1")
-    single, st2 = s.render(W, H, SPP, variant=0, coop_threshold=65, overdue=-1)
+    single, st2 = s.render(W, H, SPP, variant=0, coop_threshold=65, overdue=-1, flags=rt.FLAG_COOP_SINGLE)
     assert np.array_equal(ref.view(np.uint64), single.view(np.uint64)) and st0.rays == st2.rays
 
 
@@ -453,6 +449,33 @@ def test_band_of_the_benchmark_frame_at_benchmark_spp(oracle, earth, cfg, spp, m
         assert within >= floor, (cfg, variant, within)
         if variant == 0:
             assert exact >= min_exact, (cfg, exact)
+
+
+def test_scene_destroyed_while_its_launch_is_in_flight():
+    """rt_scene_destroy with a launch in flight waits for the kernel (it reads the scene's tables) and detaches the film:
+    the film's finish / download still deliver the frame, and a film destroyed unfinished gives the scene its count back."""
+    import ctypes as C
+    L = rt.lib()
+    w, h, spp = 256, 128, 16
+    want, _ = rt.builtin_scene(0, 0, w, h).render(w, h, spp, variant=0)
+    scene = rt.builtin_scene(0, 0, w, h)
+    film = rt.Film(w, h)
+    film.launch(scene, film.params(spp, variant=0))
+    film._scene = None                # what Film.launch keeps alive on purpose: drop it, then the scene itself
+    L.rt_scene_destroy(scene._p)
+    scene._p = None
+    st = film.finish()
+    assert st.samples == w * h * spp
+    assert np.array_equal(film.download().view(np.uint64), want.view(np.uint64))
+    # a film that goes away with its launch unfinished: the scene can be changed again afterwards
+    scene2 = rt.builtin_scene(0, 0, w, h)
+    film2 = rt.Film(w, h)
+    film2.launch(scene2, film2.params(spp, variant=0))
+    with pytest.raises(rt.RtowError):
+        scene2.Camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)   # in flight: refused
+    L.rt_film_destroy(film2._p)
+    film2._p = None
+    scene2.Camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, w / h, 0.1, 10.0)
 
 
 # ---- a scene that changes between renders (frame sequences) ----

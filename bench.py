@@ -288,6 +288,8 @@ def main():
     ap.add_argument("--emulate-ranks", type=int, default=0,
                     help="one GPU: after the headline, render rank 0..N-1 of an N-way stripe split of the frame one after "
                          "another and report max_r T_r vs T_1/N as \"emulated_scaling\"")
+    ap.add_argument("--emulate-ppw", default="", help="with --emulate-ranks: comma-separated pixels_per_wave values to repeat the "
+                                                     "emulation with (tuning; the record of record uses the library's own choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle leg (no cpu_baseline, no parity)")
     ap.add_argument("--oracle-budget", type=float, default=14.0, help="seconds of oracle work for the parity / cpu_baseline band")
     ap.add_argument("--max-depth", type=int, default=50, help="diagnostics only (the headline uses the reference's 50)")
@@ -429,15 +431,16 @@ def main():
 
     pipe_elapsed = pipelined(args.pipeline) if (world == 1 and args.pipeline > 1) else None
 
-    def emulate(n_ranks):
+    def emulate(n_ranks, **override):
         """Rank r of an n_ranks-way stripe split of the BASELINE frame, one rank after another on this one GPU."""
         per_rank, ppw = [], []
+        kn = dict(knobs, **override)
         for r in range(n_ranks):
             f = rt.Film(W, H0, device=local_rank, stripe_rows=8, rank=r, world_size=n_ranks)
-            f.render(scene, spp, max_depth=args.max_depth, variant=variant, **knobs)   # warm-up
+            f.render(scene, spp, max_depth=args.max_depth, variant=variant, **kn)   # warm-up
             ts = []
             for _ in range(3):
-                s_ = f.render(scene, spp, max_depth=args.max_depth, variant=variant, **knobs)
+                s_ = f.render(scene, spp, max_depth=args.max_depth, variant=variant, **kn)
                 ts.append(s_.seconds_seed + s_.seconds_render)
             per_rank.append(float(np.min(ts)) * 1e3)   # best of three: a rank's frame is short, the first one after a switch of films often slow
             ppw.append(int(s_.pixels_per_wave))
@@ -496,6 +499,10 @@ def main():
                 "speedup": t1_ms / max(per_rank), "efficiency": t1_ms / max(per_rank) / args.emulate_ranks,
                 "note": "rank r's stripes rendered alone on this one GPU (seed + render kernels, HIP events); an N-GPU run "
                         "finishes with its slowest rank plus one gather of a few MB"}
+            for v in [int(x) for x in args.emulate_ppw.split(",") if x.strip()]:
+                pr, _ = emulate(args.emulate_ranks, pixels_per_wave=v)
+                out.setdefault("emulated_scaling_by_pixels_per_wave", {})[str(v)] = {
+                    "per_rank_ms": pr, "max_rank_ms": max(pr), "speedup": t1_ms / max(pr), "efficiency": t1_ms / max(pr) / args.emulate_ranks}
         if world == 1 and not args.no_cpu_baseline:
             base, stats, want, rows = oracle_band(wl, spp, args.max_depth, earth, args.oracle_budget)
             out["cpu_baseline"] = base

@@ -239,6 +239,8 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.tree_bvh, d.tree_bvh);
     up(f.nodes, d.nodes);
     up(f.fast_nodes, d.fast_nodes);
+    up(f.fast_order, d.fast_order);
+    up(f.seg_media, d.seg_media);
     up(f.world_items, d.world_items);
     up(f.materials, d.materials);
     up(f.textures, d.textures);
@@ -267,6 +269,8 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.ms_padded = f.ms_padded;
     d.n_fast_nodes = (uint32_t)f.fast_nodes.size();
     if (f.fast_nodes.empty()) d.fast_nodes = nullptr;
+    d.n_seg_media = (uint32_t)f.seg_media.size();
+    d.lds_fast_order = d.lds_seg_media = kNone;
     d.n_media = (uint32_t)f.media.size();
     d.n_materials = (uint32_t)f.materials.size();
     d.n_perlin = (uint32_t)f.perlin.size();
@@ -673,10 +677,10 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         if (tune_set("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;
             const char *name[24] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
-                                    "    record+xforms", "    box", "    sub-BVH", "    other geometry", "", "", "", "",
-                                    "box pass", "medium pass", "object pass", "primitive pass", "  hit record", "  scatter",
+                                    "    record+xforms", "    box", "    sub-BVH", "    other geometry", "between walks again", "limited node pass", "", "",
+                                    "box pass", "medium pass / between walks", "object pass", "primitive pass", "  hit record", "  scatter",
                                     "  next camera ray", "  pixel done"};
-            if (f.last_kernel.kind >= 16) {  // sphere-list kernel: slots 0 / 1 are its two scans
+            if ((f.last_kernel.kind & 63) >= 16) {  // sphere-list kernel: slots 0 / 1 are its two scans
                 name[0] = "scan, pixel-parallel";
                 name[1] = "scan, cooperative";
             }

@@ -107,13 +107,30 @@ struct BvhNodeRec { double xlo, xhi, ylo, yhi, zlo, zhi; uint32_t a, b, escape, 
 // array: every node carries, for each of the eight sign octants of the ray direction, the node to go to when its box is hit
 // (the near child) and when it is not / when its subtree is done (the escape) -- the near-first order depends only on
 // the octant.  88 bytes: the box, two leaf refs (bottom nodes hold one or two primitives; a = REF_INNER marker otherwise),
-// 8 x {hit, escape} as 16-bit node indices (0xFFFF = the walk is over).
+// 8 x {hit, escape} as 16-bit node indices (escape 0xFFFF = the walk is over; hit of a bottom node: kFastBottom | kind << 12).
 struct FastNodeRec {
     double xlo, xhi, ylo, yhi, zlo, zhi;
     uint32_t a, b;
     uint16_t link[8][2];
 };
 constexpr uint32_t kFastEnd = 0xFFFFu;
+constexpr uint32_t kFastBottom = 0x8000u;    // hit link of a bottom node: this bit | kind of its first leaf << 12 (the lane parks there)
+constexpr uint32_t kFastMaxNodes = 0x8000u;  // node indices stay below kFastBottom
+
+// The same tree over the SURFACE leaves of a BVH world that also holds ConstantMedium leaves (the Book-2 final scene: 400
+// boxes, spheres, an instanced cluster, and two media).  Only a medium's test draws random numbers, so only for the media
+// does it matter what the reference has found before it reaches them: the closest hit among the leaves that PRECEDE the
+// medium in the reference's fixed visiting order (world_items order; the BVH only prunes).  The surfaces between two
+// media are one segment whose closest hit may be searched in any order.  A ray therefore walks the library's tree once
+// per segment, restricted to the segment's range of leaf positions -- and a medium whose boundary the ray's line cannot
+// meet (slab test of its padded box) splits nothing: for most rays of that scene, one walk (render.hip seg_advance).
+// FastOrder: per node of fast_nodes, the range of leaf positions below it and the positions of a bottom node's two leaves.
+struct FastOrder { uint16_t omin, omax, oa, ob; };
+// One medium leaf, in visiting order: its position among the world's leaves, its object record, whether the reference calls
+// it twice in a row (the duplicated leaf of a span-1 node, R/BvhNode.h:63-67), and its bounding box padded outwards.
+struct SegMedium { double lo[3], hi[3]; uint32_t order, object, twice, pad; };
+constexpr uint32_t kSegMaxMedia = 4;
+constexpr uint32_t kSegEnd = 0xFFFFu;  // "to the end of the list" as an upper bound of a segment
 
 // Materials (R/Material.h, R/Metal.h, R/Dielectric.h)
 enum : uint32_t { MAT_LAMBERTIAN = 0u, MAT_METAL = 1u, MAT_DIELECTRIC = 2u, MAT_DIFFUSE_LIGHT = 3u, MAT_ISOTROPIC = 4u };
@@ -161,8 +178,11 @@ struct DeviceScene {
     const MediumRec *media;
     const GroupBox *group_boxes;
     const BvhNodeRec *nodes;
-    const FastNodeRec *fast_nodes;  // nullptr unless the world is a BVH of primitives only (see FastNodeRec)
+    const FastNodeRec *fast_nodes;  // nullptr unless the world has a library tree (see FastNodeRec, FastOrder)
     uint32_t n_fast_nodes;
+    const FastOrder *fast_order;    // SCENE_SEGMENTED: parallel to fast_nodes
+    const SegMedium *seg_media;     // SCENE_SEGMENTED: the world's medium leaves in visiting order
+    uint32_t n_seg_media;
     const TreeNodeRec *tree_nodes;
     const uint32_t *tree_items;   // children of TN_LIST nodes (tree node indices)
     const BvhNodeRec *tree_bvh;   // threaded nodes of the BvhNodes inside trees (a table of their own: nodes[] starts with the world's)
@@ -190,6 +210,7 @@ struct DeviceScene {
     // dynamic LDS block, set by the launcher per table; kNone = read the global table.
     uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin, lds_spheres_tab, lds_group_boxes,
         lds_mspheres, lds_msphere_aux, lds_sphere_aux;  // the primitive tables of a sphere world (library-tree kernel, one workgroup per CU)
+    uint32_t lds_fast_order, lds_seg_media;             // segmented walk: both always staged (render.hip launch_one)
     uint32_t flags;
 };
 
@@ -200,6 +221,7 @@ enum : uint32_t {
     SCENE_MS_UNIT_TIME = 8u,      // every moving-sphere row has time0 = 0, time1 - time0 = 1: frac == ray time
     SCENE_HAS_TREES = 32u,        // some leaf is a REF_TREE: rendered by the nested instantiations
     SCENE_WORLD_MSPHERES = 16u,   // WORLD_BVH of spheres / unit-time moving spheres only: ms_planes is filled
+    SCENE_SEGMENTED = 64u,        // WORLD_BVH with composite leaves: fast_nodes / fast_order / seg_media describe the segmented walk
 };
 
 } // namespace rtow

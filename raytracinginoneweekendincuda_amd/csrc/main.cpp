@@ -184,9 +184,14 @@ int main(int argc, char **argv)
                          "usage: rtow [--scene 0..11] [--width W] [--height H] [--spp N] [--depth D] [--seed S]\n"
                          "            [--world bvh|list] [--variant strict|fast] [--device N] [--gpus N] [--output file.ppm]\n"
                          "            [--earth decoded.ppm | --earth-bytes texture.ppm] [--accelerate-lists] [--flags N]\n"
-                         "  --earth        binary PPM (P6) of earthmap.jpg as decoded to 8-bit sRGB (e.g. `djpeg earthmap.jpg`); it is\n"
-                         "                 linearised and re-quantised exactly as the reference's RtwImage::Load does\n"
-                         "  --earth-bytes  binary PPM (P6) that already holds the bytes RtwImage::Load hands to ImageTexture\n"
+                         "  --earth        binary PPM (P6) of earthmap.jpg decoded to 8-bit sRGB by any JPEG decoder; it is linearised and\n"
+                         "                 re-quantised exactly as the reference's RtwImage::Load does.  Decoders differ: libjpeg's (djpeg)\n"
+                         "                 IDCT and chroma upsampling are not stb_image's, so ~0.6 %% of the bytes come out 1-3 off the\n"
+                         "                 reference's and the texture is near-identical, not bit-identical (parity unpinned on that path)\n"
+                         "  --earth-bytes  binary PPM (P6) that already holds the bytes RtwImage::Load hands to ImageTexture; with the\n"
+                         "                 bytes the reference's own stb_image build decodes (tests/golden/earthmap_stb.npz, written out\n"
+                         "                 by tests/golden/make_earth_golden.py) this is the only input that reproduces the reference's\n"
+                         "                 texture bit for bit\n"
                          "  --accelerate-lists  render a list world of primitives through the library's tree (same picture, faster)\n"
                          "  --flags        RT_FLAG_* bits of include/rtow.h (none of them changes the picture)\n");
             return 2;

@@ -52,11 +52,15 @@ namespace {
 //              768 threads per CU -- three waves per SIMD as before, but one copy of the scene tables in the CU's 160 KB of LDS
 //              instead of three in 52 KB each: besides the node rows, the box rows and the sphere table fit as well
 //   FAST       primitive-only BVH world walked through the library's own SAH tree, near child first (flat_scene.h FastNodeRec)
+//              (with COMPOSITE and BATCH: the segmented walk of a composite world, Traits::SEG)
 //   GROUPED    list scan with the leaves of every ray dealt to several lanes (scan_leaves_grouped): launches with pixels_per_wave < 64
 template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false, bool NESTED_ = false,
           int BLOCK_ = 256, bool FAST_ = false, bool GROUPED_ = false>
 struct Traits {
     static constexpr bool GROUPED = GROUPED_ && WORLD_ == 1 && !MEDIA_ && !NESTED_;
+    // segmented walk (flat_scene.h FastOrder / SegMedium): the library's tree over the surface leaves of a composite BVH world,
+    // walked once per run of leaves between two media; kind-batched leaf phases, one 768-thread workgroup per CU
+    static constexpr bool SEG = FAST_ && COMPOSITE_ && BATCH_ && WORLD_ == 0 && BLOCK_ >= 768;
     static constexpr bool FAST = FAST_ && !COMPOSITE_ && WORLD_ == 0;
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool NESTED = NESTED_ && COMPOSITE_;
@@ -552,8 +556,11 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
 
 // Composite leaf: instance chain and, for media, the stochastic volume hit (R/ConstantMedium.h:52-94).
 // MED: what the caller knows about the leaf -- 1 a ConstantMedium, 0 not one, -1 look at the object record.
-template <class T, int MED = -1>
-DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
+// object_span: the geometric part -- the instance chain, then one closest-hit query over [tmin, tmax] for a surface (t1, pref)
+// or, for a medium, the two boundary queries of R/ConstantMedium.h:58-64 (t1, t2, unclipped).  false: nothing hit.
+template <class T, int MED>
+DEV bool object_span(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, bool &medium, MediumRec &med, uint32_t &medium_index,
+                     double &t1, double &t2, uint32_t &pref PH_ARG)
 {
 #if RT_PHASES
     const unsigned long long ph_o0 = __builtin_readcyclecounter();
@@ -569,10 +576,11 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     }
 #endif
     // surfaces: one closest-hit query over [tmin, tmax]; media: two boundary queries (R/ConstantMedium.h:58-64)
-    const bool medium = T::MEDIA && (MED < 0 ? o.medium != kNone : MED == 1);
-    double t1 = 0.0, t2 = 0.0;
-    uint32_t pref = kNone;
-    MediumRec med{};
+    medium = T::MEDIA && (MED < 0 ? o.medium != kNone : MED == 1);
+    medium_index = o.medium;
+    t1 = 0.0;
+    t2 = 0.0;
+    pref = kNone;
     if (medium) med = get_medium(sc, o.medium);
     if (medium && o.geom_kind == GEOM_SINGLE && (o.first >> kRefShift) == REF_SPHERE) {
         // The usual boundary: one sphere.  Both queries of R/ConstantMedium.h:58-64 share oc, b, c and the
@@ -606,6 +614,17 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
             if (!medium) break;
         }
     }
+    return true;
+}
+
+template <class T, int MED = -1>
+DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
+{
+    bool medium;
+    MediumRec med{};
+    uint32_t medium_index, pref;
+    double t1, t2;
+    if (!object_span<T, MED>(sc, oi, r, tmin, tmax, medium, med, medium_index, t1, t2, pref PH_PASS)) return false;
     if (!medium) {
         best.t = t1;
         best.ref = pref;
@@ -624,9 +643,25 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     double hit_dist = med.neg_inv_density * (double)lg;
     if (hit_dist > inside) return false;
     best.t = t1 + hit_dist / ray_len;
-    best.ref = make_ref(REF_MEDIUM, o.medium);
+    best.ref = make_ref(REF_MEDIUM, medium_index);
     best.obj = oi;
     return true;
+}
+
+// Would ConstantMedium::Hit (R/ConstantMedium.h:52-94) get as far as its draw for this ray with this [tmin, tmax]?  The same
+// boundary queries and the same clipping as object_test, nothing drawn; t_exit = the second boundary hit, unclipped.
+template <class T>
+DEV bool medium_ahead(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, double &t_exit PH_ARG)
+{
+    bool medium;
+    MediumRec med{};
+    uint32_t medium_index, pref;
+    double t1, t2;
+    if (!object_span<T, 1>(sc, oi, r, tmin, tmax, medium, med, medium_index, t1, t2, pref PH_PASS)) return false;
+    t_exit = t2;
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    return !(t1 >= t2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1009,11 +1044,27 @@ DEV void walk_node_fast(const Ray &r, double tmin, Walk &w)
     const double xlo = *reinterpret_cast<const double *>(lds_raw + base), xhi = *reinterpret_cast<const double *>(lds_raw + base + 8u);
     const double ylo = *reinterpret_cast<const double *>(lds_raw + base + 16u), yhi = *reinterpret_cast<const double *>(lds_raw + base + 24u);
     const double zlo = *reinterpret_cast<const double *>(lds_raw + base + 32u), zhi = *reinterpret_cast<const double *>(lds_raw + base + 40u);
-    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 48u);
     const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
     const bool hit = box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
     const uint32_t first = links & 0xFFFFu, esc = links >> 16;
-    const uint32_t down = (na >> kRefShift) == REF_INNER ? first : (n | kWalkParked);
+    const uint32_t down = (first & kFastBottom) ? (n | kWalkParked) : first;  // a bottom node's hit link says "park here"
+    const uint32_t next = esc == kFastEnd ? kNone : esc;
+    w.state = hit ? down : next;
+}
+// The same for the segmented walk's usual case -- no limit on the leaf positions: the parked state carries the kind of the
+// pending leaf (kind-batched leaf phases), which the bottom node's hit link holds in the place the state wants it.
+static_assert(kFastBottom << 16 == kWalkParked && kWalkKindShift == 28, "hit link of a bottom node << 16 = parked bit | kind");
+DEV void walk_node_open(const Ray &r, double tmin, Walk &w)
+{
+    const uint32_t n = w.state;
+    const uint32_t base = __umul24(n, kFastNodeBytes);
+    const double xlo = *reinterpret_cast<const double *>(lds_raw + base), xhi = *reinterpret_cast<const double *>(lds_raw + base + 8u);
+    const double ylo = *reinterpret_cast<const double *>(lds_raw + base + 16u), yhi = *reinterpret_cast<const double *>(lds_raw + base + 24u);
+    const double zlo = *reinterpret_cast<const double *>(lds_raw + base + 32u), zhi = *reinterpret_cast<const double *>(lds_raw + base + 40u);
+    const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
+    const bool hit = box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
+    const uint32_t first = links & 0xFFFFu, esc = links >> 16;
+    const uint32_t down = (first & kFastBottom) ? (n | (first << 16)) : first;
     const uint32_t next = esc == kFastEnd ? kNone : esc;
     w.state = hit ? down : next;
 }
@@ -1059,6 +1110,47 @@ DEV void walk_leaves_fast(const DeviceScene &sc, const Ray &r, double tmin, Walk
     w.state = next;
 }
 
+// ---- segmented walk of a composite world (Traits::SEG) ----------------------------------------------------------------
+// The same near-child-first walk over 88-byte rows, restricted to the leaves whose position in the reference's visiting
+// order is below `hi` (the walk that leads up to a medium: what follows the medium in that order must not be seen yet):
+// a node all of whose leaves come later counts as a box miss.  A bottom node parks the lane on its first leaf that is
+// allowed (kWalkSecond set when that is leaf b).  Positions have no lower limit: a leaf met again by a later walk of the
+// same ray answers as before or not at all (its test is repeated with the closest hit it helped to find).
+DEV uint32_t leaf_kind(uint32_t ref);
+constexpr uint32_t kWalkSecond = 0x40000000u;  // parked on the bottom node's SECOND leaf
+DEV void walk_node_seg(const DeviceScene &sc, const Ray &r, double tmin, Walk &w, uint32_t hi)
+{
+    const uint32_t n = w.state;
+    const uint32_t base = __umul24(n, kFastNodeBytes);
+    const double xlo = *reinterpret_cast<const double *>(lds_raw + base), xhi = *reinterpret_cast<const double *>(lds_raw + base + 8u);
+    const double ylo = *reinterpret_cast<const double *>(lds_raw + base + 16u), yhi = *reinterpret_cast<const double *>(lds_raw + base + 24u);
+    const double zlo = *reinterpret_cast<const double *>(lds_raw + base + 32u), zhi = *reinterpret_cast<const double *>(lds_raw + base + 40u);
+    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 48u);
+    const uint32_t nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 52u);
+    const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
+    const uint32_t span = *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_fast_order + n * 8u);        // omin | omax << 16
+    const uint32_t leaves = *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_fast_order + n * 8u + 4u);  // oa | ob << 16
+    const bool inner = (na >> kRefShift) == REF_INNER;
+    const uint32_t oa = leaves & 0xFFFFu, ob = leaves >> 16;
+    const bool a_in = oa < hi, b_in = nb != kNone && ob < hi;
+    const bool in_range = inner ? (span & 0xFFFFu) < hi : (a_in || b_in);
+    const bool hit = in_range && box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
+    const uint32_t first = links & 0xFFFFu, esc = links >> 16;
+    const uint32_t pending = a_in ? na : nb;
+    const uint32_t park = n | kWalkParked | (a_in ? 0u : kWalkSecond) | (leaf_kind(pending) << kWalkKindShift);
+    const uint32_t next = esc == kFastEnd ? kNone : esc;
+    w.state = hit ? (inner ? first : park) : next;
+}
+// the pending leaf of a lane parked by walk_node_seg
+DEV uint32_t seg_pending_leaf(uint32_t state)
+{
+    return *reinterpret_cast<const uint32_t *>(lds_raw + __umul24(state & 0x0FFFFFFFu, kFastNodeBytes) + ((state & kWalkSecond) ? 52u : 48u));
+}
+struct SegState {
+    uint32_t lo, hi;  // the walk in progress (or just completed) covers the leaf positions [lo, hi); hi == kSegEnd: the ray's last walk
+    uint32_t stage;   // next medium (index into seg_media) the ray has to deal with
+};
+
 // Composite worlds: the leaf phase runs one KIND of leaf at a time.  A box, a medium, an instance and a plain primitive
 // are four different pieces of code; tested in one divergent pass the wave executes each of them with the few lanes
 // that happen to stand on that kind (measured on the Book-2 final scene: 12-16 of 64 lanes per pass).  So a parked
@@ -1067,7 +1159,6 @@ DEV void walk_leaves_fast(const DeviceScene &sc, const Ray &r, double tmin, Walk
 // look at the shading queue).  Each lane still meets its own leaves in the reference's order -- only when the wave
 // executes them changes -- so the RNG draws of media are consumed exactly as before.
 enum : uint32_t { LK_BOX = 0u, LK_MEDIUM = 1u, LK_OBJECT = 2u, LK_PRIM = 3u };
-constexpr uint32_t kWalkSecond = 0x40000000u;  // parked on the bottom node's SECOND leaf
 constexpr uint32_t kWalkNodeMask = 0x0FFFFFFFu;
 DEV uint32_t leaf_kind(uint32_t ref)
 {
@@ -1117,11 +1208,19 @@ DEV bool leaf_test_kind(const DeviceScene &sc, uint32_t ref, const Ray &r, doubl
 template <class T, uint32_t K>
 DEV void walk_leaf_pass(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng,
                         uint32_t ref PH_ARG, bool have_first = false, bool first_found = false, double first_t = 0.0,
-                        uint32_t first_ref = kNone)
+                        uint32_t first_ref = kNone, uint32_t seg_lo = 0u, uint32_t seg_hi = 0u)
 {
     const uint32_t n = w.state & kWalkNodeMask;
     uint32_t nb, next;
-    if (nv.in_lds) {
+    [[maybe_unused]] bool b_in = false;  // segmented walk: the node's second leaf lies in the interval being walked
+    if constexpr (T::SEG) {
+        const uint32_t base = __umul24(n, kFastNodeBytes);
+        nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 52u);
+        const uint32_t esc = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off) >> 16;
+        next = esc == kFastEnd ? kNone : esc;
+        const uint32_t ob = *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_fast_order + n * 8u + 4u) >> 16;
+        b_in = nb != kNone && ob < seg_hi;
+    } else if (nv.in_lds) {
         nb = lds_node_u32(nv.n, 1, n); next = lds_node_u32(nv.n, 2, n);
     } else {
         nb = nv.global[n].b; next = nv.global[n].escape;
@@ -1144,7 +1243,8 @@ DEV void walk_leaf_pass(const DeviceScene &sc, const NodeView &nv, const Ray &r,
             w.closest = best.t;
         }
         bool again = !second && nb != ref;
-        if constexpr (T::MEDIA) again = again || (!second && is_medium_leaf(nb));
+        if constexpr (T::SEG) again = !second && b_in;  // no leaf is held twice in the library's tree, and none is a medium
+        else if constexpr (T::MEDIA) again = again || (!second && is_medium_leaf(nb));
         if (!again) {
             w.state = next;
             break;
@@ -1169,7 +1269,7 @@ DEV double bcast(double x, int src_lane);
 DEV void wave_min(double &t, uint32_t &k);
 template <class T>
 DEV void walk_object_pass(const DeviceScene &sc, const NodeView &nv, const Ray &r, double tmin, Walk &w, HitInfo &best, Xorwow &rng,
-                          uint32_t pending, bool mine, uint32_t lane PH_ARG)
+                          uint32_t pending, bool mine, uint32_t lane PH_ARG, uint32_t seg_lo = 0u, uint32_t seg_hi = 0u)
 {
     ObjectRec o{};
     Ray lr = r;
@@ -1245,7 +1345,61 @@ DEV void walk_object_pass(const DeviceScene &sc, const NodeView &nv, const Ray &
             found_ref = make_ref(REF_SPHERE, first + bk);
         }
     }
-    if (mine) walk_leaf_pass<T, LK_OBJECT>(sc, nv, r, tmin, w, best, rng, pending PH_PASS, coop, found, found_t, found_ref);
+    if (mine) walk_leaf_pass<T, LK_OBJECT>(sc, nv, r, tmin, w, best, rng, pending PH_PASS, coop, found, found_t, found_ref, seg_lo, seg_hi);
+}
+
+// Segmented walk: what a ray does between two walks.  Called when the lane has no walk in progress -- a new ray, or the walk
+// over the leaf positions [sg.lo, sg.hi) has just ended.  It deals with the world's media in visiting order:
+//   * a medium whose padded bounding box the ray does not cross between 0 and the closest hit so far cannot answer:
+//     ConstantMedium::Hit clips its two boundary hits to [tMin, tMax] and returns false, before its draw, unless t1 < t2
+//     is left (R/ConstantMedium.h:66-71) -- and both boundary hits lie inside the box.  The reference's call would return
+//     false without a draw, so the medium is skipped and the surfaces on both sides of it are one segment;
+//   * the same when its own boundary queries and clipping, evaluated with the closest hit so far, already say so
+//     (medium_ahead; the closest hit can only come nearer, which clips more);
+//   * otherwise the surfaces that precede it are walked first, as far as they can matter (their closest hit is the tMax the
+//     reference calls the medium with), then the medium is tested -- twice where the reference's span-1 node holds it
+//     twice -- with the reference's own arithmetic and draws (object_test);
+//   * after the last medium, one walk over the rest of the list.
+// The reference reaches a medium only through its BVH, i.e. only if the boxes of the nodes above it are hit within the
+// closest hit so far; a medium inside a box the ray misses, or one that lies wholly beyond the closest hit, returns false
+// before its draw here as well (no boundary hit, or t1 >= t2 after clipping to tMax), so the draws are the same ones.
+template <class T>
+DEV void seg_advance(const DeviceScene &sc, const Ray &ray, Walk &w, HitInfo &best, Xorwow &rng, SegState &sg PH_ARG)
+{
+    uint32_t lo = sg.hi, hi, stage = sg.stage;
+    w.closest = w.any ? best.t : DBL_MAX;  // a walk that led up to a medium ran under a lowered bound (below): back to the closest hit itself
+    for (;;) {
+        if (stage >= sc.n_seg_media) {
+            hi = kSegEnd;
+            break;
+        }
+        const SegMedium m = lds_row<SegMedium>(sc.lds_seg_media, stage);
+        double t_exit = 0.0;
+        if (!box_test(m.lo[0], m.hi[0], m.lo[1], m.hi[1], m.lo[2], m.hi[2], ray, w.inv, 0.0, w.closest) ||
+            !medium_ahead<T>(sc, m.object, ray, 0.001, w.closest, t_exit PH_PASS)) {
+            stage++;  // it would return false before its draw: no medium here for this ray
+            continue;
+        }
+        if (lo < m.order) {
+            // The surfaces before it first -- but only as far as the medium's far side: the closest hit among them is the tMax
+            // of the medium's call, which clips the far boundary hit to it (t2 = min(t2, tMax)); a hit beyond t_exit changes
+            // nothing there, and the ray's last walk finds it again.
+            hi = m.order;
+            w.closest = fmin(w.closest, t_exit);
+            break;
+        }
+        for (uint32_t c = 0; c <= m.twice; c++)
+            if (object_test<T, 1>(sc, m.object, ray, 0.001, w.closest, best, rng PH_PASS)) {
+                w.any = true;
+                w.closest = best.t;
+            }
+        lo = m.order + 1u;
+        stage++;
+    }
+    sg.lo = lo;
+    sg.hi = hi;
+    sg.stage = stage;
+    w.state = (lo < hi && lo < sc.n_world_items) ? 0u : kNone;  // from the root, or nothing to walk
 }
 
 // HittableList world (R/HittableList.h:39-57): the item index is wave-uniform, so the primitive rows
@@ -2410,6 +2564,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             __builtin_assume(sc.lds_boxes != kNone && sc.lds_objects != kNone && sc.lds_xforms != kNone);
             __builtin_assume(sc.lds_media != kNone && sc.lds_materials != kNone && sc.lds_perlin != kNone);
             __builtin_assume(sc.lds_spheres_tab != kNone && sc.lds_group_boxes != kNone);
+            if constexpr (T::SEG) __builtin_assume(sc.lds_fast_order != kNone && sc.lds_seg_media != kNone);
         }
 #endif
     }
@@ -2440,6 +2595,17 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                 stage(sc.lds_materials, sc.materials, sc.n_materials * (uint32_t)sizeof(MaterialRec));
                 __syncthreads();
             }
+        } else if constexpr (T::SEG) {
+            // segmented walk: the library's tree over the surface leaves (rows as they are), the leaf positions per node, the media
+            auto copy = [](uint32_t off, const void *table, uint32_t bytes) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw + off);
+                const uint32_t *src = static_cast<const uint32_t *>(table);
+                for (uint32_t w = threadIdx.x; w < bytes / 4u; w += blockDim.x) dst[w] = src[w];
+            };
+            copy(0u, sc.fast_nodes, sc.n_fast_nodes * kFastNodeBytes);
+            copy(sc.lds_fast_order, sc.fast_order, sc.n_fast_nodes * (uint32_t)sizeof(FastOrder));
+            copy(sc.lds_seg_media, sc.seg_media, sc.n_seg_media * (uint32_t)sizeof(SegMedium));
+            nv.n = sc.n_fast_nodes;
         } else if (nv.in_lds) {
             const uint32_t n = sc.n_world_nodes;
             for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
@@ -2536,6 +2702,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     walk_best.t = 0.0;
     walk_best.ref = kNone;
     walk_best.obj = kNone;
+    [[maybe_unused]] SegState seg{0u, kSegEnd, 0u};  // segmented walk: hi == kSegEnd also means "nothing more to walk" for an idle lane
 
 #if RT_STAMP
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicMin(a.ray_counter + 5, (unsigned long long)wall_clock64());
@@ -2625,6 +2792,10 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                         active = true;
                         if constexpr (T::WORLD == 0) {
                             walk_begin(walk, ray, DBL_MAX);
+                            if constexpr (T::SEG) {  // "between walks", before the first one: seg_advance at the head of the next round
+                                seg = SegState{0u, 0u, 0u};
+                                walk.state = kNone;
+                            }
                         }
                     }
                 }
@@ -2685,8 +2856,26 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             // +7 %, 4 is -1 %), 4 for composite ones (C5: +6 %; C4 indifferent)
             const int n_rounds = T::BATCH ? a.rounds : (T::COMPOSITE ? kRoundsComposite : (T::FAST ? kRoundsFast : kRounds));
             for (int round = 0; round < n_rounds; round++) {
+                if constexpr (T::SEG) {
+                    // between two walks (a new ray, or a walk that was not the ray's last has ended): the media that are due, then
+                    // the next walk (seg_advance) -- the one place where media are tested and draw
+                    const bool between = active && walk.state == kNone && seg.hi != kSegEnd;
+                    if (__any(between)) {
+                        PH_BEGIN();
+#if RT_PHASES
+                        const bool ph_again = between && seg.hi != 0u;  // not the ray's first time here: a limited walk has ended
+#endif
+                        if (between) seg_advance<T>(sc, ray, walk, walk_best, rng, seg PH_PASS);
+                        PH_END(17, between);
+#if RT_PHASES
+                        if (__any(ph_again)) PH_END(12, ph_again);
+#endif
+                    }
+                }
                 for (int step = 0; step < (T::COMPOSITE ? a.node_burst : kBurst); step++) {
                     const bool mover = walk_moving(walk.state);
+                    [[maybe_unused]] bool limited_walks = false;
+                    if constexpr (T::SEG) limited_walks = __any(mover && seg.hi != kSegEnd);
 #if RT_SIMPLE_BREAK
                     if (!__any(mover)) break;
 #else
@@ -2698,6 +2887,9 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #endif
                     {
                         PH_BEGIN();
+#if RT_PHASES
+                        if (limited_walks) PH_END(13, mover && seg.hi != kSegEnd);
+#endif
                         if (mover) {
                             if constexpr (T::FAST) {
                                 walk_node_fast(ray, 0.001, walk);
@@ -2705,13 +2897,21 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #if RT_FAST_VISITS >= 3
                                 if (walk_moving(walk.state)) walk_node_fast(ray, 0.001, walk);
 #endif
+                            } else if constexpr (T::SEG) {
+                                if (limited_walks) {  // some lane of the wave is on its way to a medium (wave-uniform, rare)
+                                    walk_node_seg(sc, ray, 0.001, walk, seg.hi);
+                                    if (walk_moving(walk.state)) walk_node_seg(sc, ray, 0.001, walk, seg.hi);
+                                } else {
+                                    walk_node_open(ray, 0.001, walk);
+                                    if (walk_moving(walk.state)) walk_node_open(ray, 0.001, walk);
+                                }
                             } else
                             walk_node<T::BATCH>(nv, ray, 0.001, walk);
                             // Primitive worlds (deep BVH, cheap leaves): a second visit before the next look at the
                             // wave's state -- the ballots and counts that steer the phases cost a fifth of a node visit.
                             // Not for composite worlds: the Cornell box's tree is three levels deep (measured -17 %).
                             // Kind-batched kernels run on deep trees too: the same second visit (C5 +x %).
-                            if constexpr ((!T::COMPOSITE || T::BATCH) && !T::FAST) {
+                            if constexpr ((!T::COMPOSITE || T::BATCH) && !T::FAST && !T::SEG) {
                                 if (walk_moving(walk.state)) walk_node<T::BATCH>(nv, ray, 0.001, walk);
                             }
                         }
@@ -2731,19 +2931,21 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                             if (waiting > 0 && (serve_all || waiting >= a.leaf_batch)) {                               \
                                 PH_BEGIN();                                                                            \
                                 if (mine) walk_leaf_pass<T, (K)>(sc, nv, ray, 0.001, walk, walk_best, rng,             \
-                                                                 walk_pending_leaf(nv, walk.state) PH_PASS);           \
+                                                                 T::SEG ? seg_pending_leaf(walk.state) : walk_pending_leaf(nv, walk.state) PH_PASS, \
+                                                                 false, false, 0.0, kNone, seg.lo, seg.hi);            \
                                 PH_END(SLOT, mine);                                                                    \
                             }                                                                                          \
                         }
                         RT_LEAF_PASS(LK_BOX, 16)
-                        if constexpr (T::MEDIA) RT_LEAF_PASS(LK_MEDIUM, 17)
+                        if constexpr (T::MEDIA && !T::SEG) RT_LEAF_PASS(LK_MEDIUM, 17)  // segmented walk: no medium is a leaf of the tree
                         {  // instances and groups: the whole wave takes part (walk_object_pass)
                             const bool mine = at_leaf && kind == LK_OBJECT;
                             const int waiting = __popcll(__ballot(mine));
                             if (waiting > 0 && (serve_all || waiting >= a.object_batch)) {
                                 PH_BEGIN();
                                 walk_object_pass<T>(sc, nv, ray, 0.001, walk, walk_best, rng,
-                                                    mine ? walk_pending_leaf(nv, walk.state) : kNone, mine, lane PH_PASS);
+                                                    mine ? (T::SEG ? seg_pending_leaf(walk.state) : walk_pending_leaf(nv, walk.state)) : kNone, mine,
+                                                    lane PH_PASS, seg.lo, seg.hi);
                                 PH_END(18, mine);
                             }
                         }
@@ -2759,9 +2961,13 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                     }
                     if (__any(at_leaf)) PH_END(1, at_leaf);
                 }
+                if constexpr (T::SEG) {
+                    if (!__any(walk.state != kNone || (active && seg.hi != kSegEnd))) break;
+                } else
                 if (!__any(walk.state != kNone)) break;
             }
-            const unsigned long long walkers = __ballot(walk.state != kNone);
+            // segmented walk: a lane between two walks is still on its way, not waiting to be shaded
+            const unsigned long long walkers = T::SEG ? __ballot(walk.state != kNone || (active && seg.hi != kSegEnd)) : __ballot(walk.state != kNone);
             const unsigned long long waiting = live & ~walkers;
             const int n_wait = __popcll(waiting), n_walk = __popcll(walkers);
             todo = (n_wait >= a.shade_batch || n_wait >= n_walk) ? waiting : 0ull;
@@ -2854,7 +3060,15 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             ph.t[22] += __builtin_readcyclecounter() - ph_c;  // next camera ray or pixel done (booked together)
 #endif
             if constexpr (T::WORLD == 0) {
-                if (active) walk_begin(walk, ray, DBL_MAX);
+                if (active) {
+                    walk_begin(walk, ray, DBL_MAX);
+                    if constexpr (T::SEG) {
+                        seg = SegState{0u, 0u, 0u};
+                        walk.state = kNone;
+                    }
+                } else if constexpr (T::SEG) {
+                    seg.hi = kSegEnd;  // no pixel: nothing between walks either
+                }
             }
         }
 #if RT_PHASES
@@ -3024,6 +3238,9 @@ using TBvhMedia = Traits<0, true, false, RT_WAVES_MEDIA, true>;                 
 #define RT_BLOCK_DEEP 768
 #endif
 using TBvhGeneralDeep = Traits<0, true, true, RT_WAVES_DEEP, true, true, false, RT_BLOCK_DEEP>;
+// ... and walked through the library's tree, one walk per run of surface leaves between two media (Traits::SEG): worlds that
+// flat_scene.h SCENE_SEGMENTED describes (C5)
+using TBvhSegmented = Traits<0, true, true, RT_WAVES_DEEP, true, true, false, RT_BLOCK_DEEP, true>;
 // List scans over primitives / instances without media or table-walking textures.  Also the BVH worlds of small
 // scenes: for up to 16 leaves within a cost budget (FlatScene::scan_cost) a scan of all of them in the tree's leaf order -- every lane on the same leaf, rows
 // through uniform loads, no node visits, no phases -- beats walking the tree (Cornell box: 8 leaves, 7 nodes).  Without
@@ -3070,7 +3287,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
     size_t lds = 0;
     a.lds_nodes = 0;
     if (T::WORLD == 0) {
-        size_t need = T::FAST ? (size_t)sc.n_fast_nodes * kFastNodeBytes : (size_t)sc.n_world_nodes * kLdsNodeBytes;
+        size_t need = (T::FAST || T::SEG) ? (size_t)sc.n_fast_nodes * kFastNodeBytes : (size_t)sc.n_world_nodes * kLdsNodeBytes;
         if (need <= 60 * 1024) {  // keep >= 2 workgroups (of 256 threads) per CU resident
             lds = need;
             a.lds_nodes = 1;
@@ -3102,6 +3319,14 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             if (!fits) return launch_one<TBvhPrims>(sc_in, a_in, stream, info);
             auto empty = [](uint32_t &slot) { if (slot == kNone) slot = 0; };  // an empty table is never read
             empty(sc.lds_mspheres); empty(sc.lds_msphere_aux); empty(sc.lds_spheres_tab); empty(sc.lds_sphere_aux); empty(sc.lds_materials);
+        }
+        if constexpr (T::SEG) {  // the leaf positions per node and the media, right behind the node rows
+            size_t off = (lds + 15) & ~(size_t)15;
+            sc.lds_fast_order = (uint32_t)off;
+            off += ((size_t)sc.n_fast_nodes * sizeof(FastOrder) + 15) & ~(size_t)15;
+            sc.lds_seg_media = (uint32_t)off;
+            off += ((size_t)(sc.n_seg_media ? sc.n_seg_media : 1u) * sizeof(SegMedium) + 15) & ~(size_t)15;
+            lds = off;
         }
         if (T::COMPOSITE) {
             // Small tables ride along behind the node rows, each on its own merits: the records a leaf test or the shading
@@ -3140,7 +3365,12 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
                                   (sc.n_materials == 0 || sc.lds_materials != kNone) && (sc.n_perlin == 0 || sc.lds_perlin != kNone) &&
                                   (sc.n_boxes == 0 || sc.lds_boxes != kNone) && (sc.n_spheres == 0 || sc.lds_spheres_tab != kNone);
                 // (the quad rows stay optional: a box's six faces are read only for a hit point on one of its edges)
-                if (!fits) return launch_one<TBvhGeneral>(sc_in, a_in, stream, info);
+                if constexpr (T::SEG) {  // the reference's tree in the reference's order instead
+                    if (!fits || !(sc.flags & SCENE_SEGMENTED) || sc.fast_nodes == nullptr || sc.n_seg_media > kSegMaxMedia)
+                        return launch_one<TBvhGeneralDeep>(sc_in, a_in, stream, info);
+                } else {
+                    if (!fits) return launch_one<TBvhGeneral>(sc_in, a_in, stream, info);
+                }
                 auto empty = [](uint32_t &slot) { if (slot == kNone) slot = 0; };  // an empty table is never read
                 empty(sc.lds_objects); empty(sc.lds_xforms); empty(sc.lds_media); empty(sc.lds_group_boxes); empty(sc.lds_materials);
                 empty(sc.lds_perlin); empty(sc.lds_boxes); empty(sc.lds_spheres_tab);
@@ -3162,7 +3392,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
         info->vgprs = attr.numRegs;
         info->lds_bytes = (int)(attr.sharedSizeBytes + lds);
         info->kind = T::WORLD * 8 + (T::MEDIA ? 4 : 0) + (T::COMPOSITE ? 2 : 0) + (T::RICH ? 1 : 0) + (T::NESTED ? 32 : 0) + (T::FAST ? 64 : 0) +
-                     (T::GROUPED ? 128 : 0);
+                     (T::GROUPED ? 128 : 0) + (T::SEG ? 256 : 0);
         return hipSuccess;
     }
     if (a.n_pixels == 0 || a.spp <= 0) return hipSuccess;
@@ -3194,7 +3424,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
 
 // instantiations of group 1, by id (defined in the RT_GROUP == 1 translation unit)
 enum CompositeKernel { CK_LIST_PRIMS, CK_LIST_INSTANCES, CK_LIST_GENERAL, CK_LIST_NESTED, CK_BVH_INSTANCES, CK_BVH_MEDIA,
-                       CK_BVH_GENERAL, CK_BVH_GENERAL_DEEP, CK_BVH_NESTED, CK_LIST_PRIMS_GROUPED, CK_LIST_INSTANCES_GROUPED };
+                       CK_BVH_GENERAL, CK_BVH_GENERAL_DEEP, CK_BVH_NESTED, CK_LIST_PRIMS_GROUPED, CK_LIST_INSTANCES_GROUPED, CK_BVH_SEGMENTED };
 hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info);
 
 #if RT_GROUP == 1
@@ -3211,6 +3441,7 @@ hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc
     case CK_BVH_MEDIA: return launch_one<TBvhMedia>(sc, a, stream, info);
     case CK_BVH_GENERAL: return launch_one<TBvhGeneral>(sc, a, stream, info);
     case CK_BVH_GENERAL_DEEP: return launch_one<TBvhGeneralDeep>(sc, a, stream, info);
+    case CK_BVH_SEGMENTED: return launch_one<TBvhSegmented>(sc, a, stream, info);
     default: return launch_one<TBvhNested>(sc, a, stream, info);
     }
 }
@@ -3242,6 +3473,9 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
                        ? launch_one<TBvhPrimsFast>(sc, a, stream, info)
                        : launch_one<TBvhPrims>(sc, a, stream, info);
         if (!rich && !a.force_general) return composite_kernel(media ? CK_BVH_MEDIA : CK_BVH_INSTANCES);
+        // deep worlds: the library's tree, one walk per run of surfaces between media, where the scene has one (RT_FLAG_REFERENCE_TREE:
+        // the reference's tree in the reference's order); both fall back when their tables do not fit the LDS of a CU
+        if (sc.n_world_nodes > 64 && (sc.flags & SCENE_SEGMENTED) && !a.reference_tree) return composite_kernel(CK_BVH_SEGMENTED);
         return composite_kernel(sc.n_world_nodes > 64 ? CK_BVH_GENERAL_DEEP : CK_BVH_GENERAL);
     }
     return composite_kernel(CK_LIST_GENERAL);

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 #include "../../include/rtow.h"
 #include "scene_host.h"
@@ -854,7 +855,12 @@ struct FastBuilder {
         const Node &nd = nodes[n];
         esc[n] = (uint16_t)escape;
         if (nd.left < 0) {
-            hit[n] = (uint16_t)escape;  // unused: a bottom node parks the lane; its leaves done, the walk goes to esc
+            // a bottom node parks the lane (its leaves done, the walk goes to esc): the "hit" link says so -- bit 15, and in bits
+            // 12-13 the kind of leaf a as the kind-batched kernels sort by it (render.hip leaf_kind) -- so that a node visit needs
+            // no look at the leaf refs (kFastMaxNodes keeps node indices below bit 15)
+            const uint32_t tag = nd.a >> kRefShift;
+            const uint32_t kind = tag == REF_BOX ? 0u : (tag == REF_MOBJECT ? 1u : (tag == REF_OBJECT ? 2u : 3u));
+            hit[n] = (uint16_t)(kFastBottom | (kind << 12));
             return;
         }
         const bool negative = (oct >> nd.axis) & 1;
@@ -881,7 +887,7 @@ static void build_fast_tree(FlatScene &f, bool reference_tree_only)
     std::vector<uint32_t> idx(n);
     for (size_t k = 0; k < n; k++) idx[k] = (uint32_t)k;
     fb.build(idx, 0, n);
-    if (fb.nodes.size() >= kFastEnd) return;
+    if (fb.nodes.size() >= kFastMaxNodes) return;
     f.fast_nodes.resize(fb.nodes.size());
     for (size_t k = 0; k < fb.nodes.size(); k++) {
         const FastBuilder::Node &nd = fb.nodes[k];
@@ -900,6 +906,90 @@ static void build_fast_tree(FlatScene &f, bool reference_tree_only)
             f.fast_nodes[k].link[oct][1] = esc[k];
         }
     }
+}
+
+// The segmented walk of a BVH world with composite leaves (flat_scene.h FastOrder / SegMedium): the library's tree over the
+// world's surface leaves, every node with the range of leaf positions below it, and the medium leaves in visiting order.
+static void build_segment_tree(FlatScene &f, bool reference_tree_only)
+{
+    f.fast_order.clear();
+    f.seg_media.clear();
+    if (reference_tree_only || f.world_kind != WORLD_BVH || !f.fast_nodes.empty()) return;
+    const size_t n = f.world_items.size();
+    if (n < 4 || n >= kSegEnd || (f.objects.empty() && f.boxes.empty())) return;
+    std::vector<Box> boxes;
+    std::vector<uint32_t> refs, order_of;
+    std::vector<uint32_t> media;
+    for (size_t k = 0; k < n; k++) {
+        const uint32_t tag = f.world_items[k] >> kRefShift;
+        if (tag == REF_TREE) return;  // general nesting: the interpreter's kernels
+        if (tag == REF_MOBJECT) {
+            media.push_back((uint32_t)k);
+            continue;
+        }
+        boxes.push_back(f.leaf_boxes[k]);
+        refs.push_back(f.world_items[k]);
+        order_of.push_back((uint32_t)k);
+    }
+    if (media.size() > kSegMaxMedia || refs.size() < 3) return;
+    FastBuilder fb{boxes, refs, {}};
+    std::vector<uint32_t> idx(refs.size());
+    for (size_t k = 0; k < idx.size(); k++) idx[k] = (uint32_t)k;
+    fb.build(idx, 0, idx.size());
+    if (fb.nodes.size() >= kFastMaxNodes) return;
+    // position of a leaf ref in the world's list (refs are unique: every leaf was lowered once)
+    std::unordered_map<uint32_t, uint32_t> position_of;
+    for (size_t k = 0; k < refs.size(); k++) position_of[refs[k]] = order_of[k];
+    auto position = [&](uint32_t ref) -> uint32_t { return position_of.at(ref); };
+    f.fast_nodes.resize(fb.nodes.size());
+    f.fast_order.resize(fb.nodes.size());
+    for (size_t k = fb.nodes.size(); k-- > 0;) {  // children follow their parent in the array: bottom-up by going backwards
+        const FastBuilder::Node &nd = fb.nodes[k];
+        FastNodeRec &r = f.fast_nodes[k];
+        r.xlo = nd.box.lo[0]; r.xhi = nd.box.hi[0];
+        r.ylo = nd.box.lo[1]; r.yhi = nd.box.hi[1];
+        r.zlo = nd.box.lo[2]; r.zhi = nd.box.hi[2];
+        r.a = nd.left < 0 ? nd.a : make_ref(REF_INNER, 0);
+        r.b = nd.left < 0 ? nd.b : make_ref(REF_INNER, 0);
+        FastOrder &o = f.fast_order[k];
+        if (nd.left < 0) {
+            o.oa = (uint16_t)position(nd.a);
+            o.ob = nd.b == kNone ? o.oa : (uint16_t)position(nd.b);
+            o.omin = std::min(o.oa, o.ob);
+            o.omax = std::max(o.oa, o.ob);
+        } else {
+            const FastOrder &l = f.fast_order[(size_t)nd.left], &rr = f.fast_order[(size_t)nd.right];
+            o.oa = o.ob = 0;
+            o.omin = std::min(l.omin, rr.omin);
+            o.omax = std::max(l.omax, rr.omax);
+        }
+    }
+    std::vector<uint16_t> hit(fb.nodes.size()), esc(fb.nodes.size());
+    for (int oct = 0; oct < 8; oct++) {
+        fb.thread(0, kFastEnd, oct, hit, esc);
+        for (size_t k = 0; k < fb.nodes.size(); k++) {
+            f.fast_nodes[k].link[oct][0] = hit[k];
+            f.fast_nodes[k].link[oct][1] = esc[k];
+        }
+    }
+    for (uint32_t k : media) {
+        SegMedium m{};
+        const Box &b = f.leaf_boxes[k];
+        for (int a = 0; a < 3; a++) {
+            // outwards by a part in 2^20 of the magnitudes involved (and at least the reference's own thin-box padding): far
+            // beyond any rounding of the slab test or of the boundary's own arithmetic
+            const double pad = 9.5367431640625e-07 * (std::fabs(b.lo[a]) + std::fabs(b.hi[a])) + 1e-4;
+            m.lo[a] = b.lo[a] - pad;
+            m.hi[a] = b.hi[a] + pad;
+        }
+        m.order = k;
+        m.object = f.world_items[k] & kRefIndexMask;
+        m.twice = 0;
+        for (uint32_t nd = 0; nd < f.n_world_nodes; nd++)  // the reference's own tree: a span-1 node holds the leaf twice
+            if (f.nodes[nd].a == f.world_items[k] && f.nodes[nd].b == f.world_items[k]) m.twice = 1;
+        f.seg_media.push_back(m);
+    }
+    f.flags |= SCENE_SEGMENTED;
 }
 
 int flatten_scene(SceneImpl &s)
@@ -998,7 +1088,11 @@ int flatten_scene(SceneImpl &s)
         }
         f.scan_cost = cost > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cost;
     }
-    build_fast_tree(f, (s.options & RT_SCENE_REFERENCE_TREE_ONLY) != 0 || has_coincident_primitives(s, leaves));
+    {
+        const bool reference_only = (s.options & RT_SCENE_REFERENCE_TREE_ONLY) != 0 || has_coincident_primitives(s, leaves);
+        build_fast_tree(f, reference_only);
+        build_segment_tree(f, reference_only);
+    }
     {
         // Rows of the list scan's conservative filter (render.hip filter_four): centre and |c|^2 - r^2, and the
         // scene's reach max(|c| + r) that bounds the filter's rounding error.  A non-finite row becomes (0, 0, 0, -inf):

@@ -79,6 +79,8 @@ struct FlatScene {
     std::vector<BvhNodeRec> tree_bvh;
     std::vector<BvhNodeRec> nodes;
     std::vector<FastNodeRec> fast_nodes;
+    std::vector<FastOrder> fast_order;   // SCENE_SEGMENTED
+    std::vector<SegMedium> seg_media;    // SCENE_SEGMENTED
     std::vector<uint32_t> world_items;   // leaf refs in final order (both world kinds)
     std::vector<Box> leaf_boxes;         // introspection
     std::vector<int> leaf_kinds;         // introspection: the leaf's kind as constructed (0 sphere, 1 moving sphere, 2 quad, 3 composite)

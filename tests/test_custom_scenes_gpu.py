@@ -224,6 +224,101 @@ def test_coincident_primitives_resolve_like_the_reference(world_kind):
             assert np.array_equal(grouped.view(np.uint64), got.view(np.uint64)), ppw
 
 
+# ---- the segmented walk of deep composite worlds with media (flat_scene.h FastOrder / SegMedium, render.hip seg_advance) ----
+def _deep_media_world(media):
+    """~110 leaves under one BvhNode: a field of plain boxes, spheres of every material, instanced boxes, an instanced cluster of
+    40 spheres (sub-BVH + cooperative scan), and ConstantMedium leaves as `media` names them:
+      mist    a sphere of radius 60 around everything, camera included (sorted first by the reference's build)
+      ball    a small glass ball with fog inside, in the middle of the field
+      crate   a rotated, translated box of smoke (boundary = six quads behind two transforms)
+      far     a ball of fog behind the camera's far wall that hardly any ray's line meets
+      lone    (extra leaves arranged so that one medium ends up alone in a span-1 node: hit twice)"""
+    def build(s, Rng):
+        rng = Rng(7)
+        u = rng.uniform
+        white, grey = s.Lambertian((0.73, 0.73, 0.73)), s.Lambertian((0.4, 0.45, 0.4))
+        items = []
+        for i in range(8):
+            for k in range(8):
+                x0, z0, h = -8.0 + 2.0 * i, -8.0 + 2.0 * k, 0.2 + 1.1 * u()
+                items.append(s.MakeBox((x0, -1.0, z0), (x0 + 1.9, -1.0 + h, z0 + 1.9), grey if (i + k) % 3 else white))
+        mats = [s.Lambertian((0.7, 0.2, 0.2)), s.Metal((0.8, 0.8, 0.9), 0.1), s.Dielectric(1.5), s.DiffuseLight((3.0, 3.0, 2.5))]
+        for k in range(16):
+            items.append(s.Sphere((-7.0 + 0.95 * k, 0.8 + 0.6 * u(), -6.0 + 12.0 * u()), 0.3 + 0.25 * u(), mats[k % 4]))
+        items.append(s.MovingSphere((3.0, 1.5, 1.0), (3.0, 2.0, 1.0), 0.0, 1.0, 0.5, mats[0]))
+        items.append(s.Quad((-4.0, 6.0, -4.0), (8.0, 0, 0), (0, 0, 8.0), s.DiffuseLight((4.0, 4.0, 4.0))))
+        for k in range(4):
+            box = s.MakeBox((0, 0, 0), (0.9, 1.6 + 0.3 * k, 0.9), white)
+            items.append(s.Translate(s.RotateY(box, 15.0 + 20.0 * k), (-5.0 + 3.0 * k, 0.4, 4.0 - 2.5 * k)))
+        cluster = [s.Sphere((1.6 * u(), 1.6 * u(), 1.6 * u()), 0.12, white) for _ in range(40)]
+        items.append(s.Translate(s.RotateY(s.HittableList(cluster), 15.0), (-1.0, 1.2, 3.0)))
+        if "mist" in media:
+            items.append(s.ConstantMedium(s.Sphere((0, 0, 0), 60.0, s.Dielectric(1.5)), 0.004, (1, 1, 1)))
+        if "ball" in media:
+            ball = s.Sphere((0.5, 1.4, 0.0), 1.0, s.Dielectric(1.5))
+            items.append(ball)
+            items.append(s.ConstantMedium(ball, 0.6, (0.2, 0.4, 0.9)))
+        if "crate" in media:
+            crate = s.Translate(s.RotateY(s.MakeBox((0, 0, 0), (1.5, 1.5, 1.5), white), -18.0), (-4.0, 0.6, -1.0))
+            items.append(s.ConstantMedium(crate, 0.9, (0.05, 0.05, 0.05)))
+        if "far" in media:
+            items.append(s.ConstantMedium(s.Sphere((30.0, 25.0, -40.0), 2.0, s.Dielectric(1.5)), 0.5, (0.9, 0.9, 0.1)))
+        if "lone" in media:
+            # the reference's median split puts a lone leaf into a span-1 node when a span of three is cut 1 + 2: three leaves far
+            # out on +x, the medium first among them by its box's lower edge
+            items.append(s.ConstantMedium(s.Sphere((40.0, 1.0, 0.0), 1.5, s.Dielectric(1.5)), 0.7, (0.9, 0.3, 0.3)))
+            items.append(s.Sphere((44.0, 1.0, 0.0), 1.0, mats[1]))
+            items.append(s.Sphere((47.0, 1.0, 0.0), 1.0, mats[0]))
+        for extra in range(media.count("more")):   # more media than the segmented walk handles: the reference-order kernel takes over
+            items.append(s.ConstantMedium(s.Sphere((-6.0 + 3.0 * extra, 3.0, -3.0), 0.5, s.Dielectric(1.5)), 0.8, (0.3, 0.9, 0.3)))
+        s.SetWorld(s.BvhNode(items))
+        s.Camera((12.0, 6.0, 14.0), (0.0, 0.5, 0.0), (0, 1, 0), 38.0, W / H, 0.05, 18.0, 0.0, 1.0, (0.35, 0.45, 0.7))
+        s.Commit()
+    return build
+
+
+@pytest.mark.parametrize("media", [("mist",), ("ball",), ("mist", "ball", "crate"), ("mist", "ball", "crate", "far"), ("lone", "ball"), ()])
+def test_segmented_walk_matches_the_oracle_and_the_reference_order_walk(media):
+    """Deep composite worlds with media go through the library's tree, one walk per run of surface leaves between two media
+    (kernel kind bit 256).  Only media draw random numbers, and each is tested with exactly the closest hit the reference has
+    when it reaches it, so frame, ray count and RNG streams equal the oracle's (which walks the reference's pointer tree in
+    the reference's order) and those of the kernel that walks the reference's tree (RT_FLAG_REFERENCE_TREE)."""
+    prod, orc = build_both(_deep_media_world(media))
+    want, stats = orc.render(W, H, 6, want_stats=True)
+    for variant in (0, 1):
+        seg, st = prod.render(W, H, 6, variant=variant, flags=2)            # RT_FLAG_FORCE_GENERAL: plain textures would pick a non-rich kernel
+        ref, st_ref = prod.render(W, H, 6, variant=variant, flags=2 | 128)
+        assert st.kernel_kind & 256, f"expected the segmented walk, got kernel kind {st.kernel_kind}"
+        assert not (st_ref.kernel_kind & 256)
+        assert st.rays == st_ref.rays
+        assert np.array_equal(seg.view(np.uint64), ref.view(np.uint64)), (media, variant)
+        if variant == 0:
+            exact, within, worst = compare(seg, want)
+            print(f"media {media}: kernel kind {st.kernel_kind}, bit-exact {exact:.4f}, within {within:.4f}, max |d| {worst:.3g}")
+            assert st.rays == stats["rays"] and within >= 0.999 and exact >= 0.98
+
+
+def test_more_media_than_the_segmented_walk_handles_fall_back():
+    prod, orc = build_both(_deep_media_world(("mist", "ball", "crate", "far", "more", "more")))
+    got, st = prod.render(W, H, 4, variant=0, flags=2)
+    assert not (st.kernel_kind & 256)
+    want = orc.render(W, H, 4)
+    exact, within, _ = compare(got, want)
+    assert within >= 0.999 and exact >= 0.98
+
+
+def test_segmented_walk_continues_the_same_rng_streams():
+    """Progressive rendering across the two walks: 3 + 5 samples with the saved per-pixel streams, one half by each kernel, equal
+    8 samples by either -- the streams (media draws included) are consumed identically."""
+    import raytracinginoneweekendincuda_amd as rt
+    prod, _ = build_both(_deep_media_world(("mist", "ball", "crate")))
+    one, _ = prod.render(W, H, 8, variant=0, flags=2)
+    film = rt.Film(W, H)
+    film.render(prod, 3, variant=0, flags=2 | rt.FLAG_ACCUMULATE)
+    film.render(prod, 5, variant=0, flags=2 | 128 | rt.FLAG_ACCUMULATE | rt.FLAG_KEEP_RNG_STATE)
+    assert np.array_equal(film.download().view(np.uint64), one.view(np.uint64))
+
+
 # ---- general nesting (R/Instance.h, R/ConstantMedium.h, R/HittableList.h, R/BvhNode.h take any Hittable*) ----
 def _room(s, items, cam_from=(0, 1.2, 6.5), cam_at=(0, 0.6, 0), vfov=50.0, bg=(0.55, 0.65, 0.9), world="bvh"):
     floor = s.Quad((-30, -1, -30), (60, 0, 0), (0, 0, 60), s.Lambertian(s.CheckerTexture(0.8, s.SolidColor((0.2, 0.3, 0.1)),

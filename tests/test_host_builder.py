@@ -234,3 +234,40 @@ def test_scene_options_are_read_at_commit():
     assert s.dump_fast_nodes()[0].shape[0] == n
     with pytest.raises(rt.RtowError):
         s.set_options(1 << 20)
+
+
+@pytest.mark.parametrize("scene_id", [0, 9])
+def test_library_tree_links_visit_every_leaf_once_in_every_octant(scene_id):
+    """The octant-threaded tree the kernels walk without a stack (flat_scene.h FastNodeRec): following, for each of the eight
+    direction octants, the hit link of every inner node and the escape link of every bottom node -- a ray that hits every box --
+    must meet every leaf exactly once and end; a bottom node's hit link says "park" (bit 15) and carries the kind of its first
+    leaf.  Scene 0: primitives only.  Scene 9: the surface leaves of the Book-2 final scene (segmented walk; the two media are
+    not in the tree), box leaves tagged as such."""
+    s = rt.builtin_scene(scene_id, 0, 64, 64)
+    boxes, ab, links = s.dump_fast_nodes()
+    n = boxes.shape[0]
+    assert 0 < n < 0x8000
+    inner = (ab[:, 0] >> 28) == 14
+    leaves_total = int((~inner).sum() + ((~inner) & (ab[:, 1] != 0xFFFFFFFF)).sum())
+    info = s.info()
+    assert leaves_total == info["n_leaves"] - info["n_media"]
+    for octant in range(8):
+        seen, node, steps = [], 0, 0
+        while node != 0xFFFF:
+            steps += 1
+            assert steps <= 2 * n, "the links loop"
+            hit, esc = int(links[node, octant, 0]), int(links[node, octant, 1])
+            if inner[node]:
+                assert hit < n
+                lo, hi = boxes[hit, 0::2], boxes[hit, 1::2]          # a child's box lies inside its parent's
+                assert (lo >= boxes[node, 0::2]).all() and (hi <= boxes[node, 1::2]).all()
+                node = hit
+            else:
+                tag = int(ab[node, 0]) >> 28
+                kind = 0 if tag == 5 else (1 if tag == 6 else (2 if tag == 3 else 3))
+                assert hit == (0x8000 | (kind << 12)), (node, hex(hit))
+                seen.append(int(ab[node, 0]))
+                if ab[node, 1] != 0xFFFFFFFF:
+                    seen.append(int(ab[node, 1]))
+                node = esc
+        assert len(seen) == leaves_total and len(set(seen)) == leaves_total, octant

@@ -241,6 +241,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.fast_nodes, d.fast_nodes);
     up(f.fast_order, d.fast_order);
     up(f.seg_media, d.seg_media);
+    up(f.seg_cand, d.seg_cand);
     up(f.world_items, d.world_items);
     up(f.materials, d.materials);
     up(f.textures, d.textures);
@@ -270,7 +271,8 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.n_fast_nodes = (uint32_t)f.fast_nodes.size();
     if (f.fast_nodes.empty()) d.fast_nodes = nullptr;
     d.n_seg_media = (uint32_t)f.seg_media.size();
-    d.lds_fast_order = d.lds_seg_media = kNone;
+    d.n_seg_cand = (uint32_t)f.seg_cand.size();
+    d.lds_fast_order = d.lds_seg_media = d.lds_seg_cand = kNone;
     d.n_media = (uint32_t)f.media.size();
     d.n_materials = (uint32_t)f.materials.size();
     d.n_perlin = (uint32_t)f.perlin.size();

@@ -128,7 +128,12 @@ constexpr uint32_t kFastMaxNodes = 0x8000u;  // node indices stay below kFastBot
 struct FastOrder { uint16_t omin, omax, oa, ob; };
 // One medium leaf, in visiting order: its position among the world's leaves, its object record, whether the reference calls
 // it twice in a row (the duplicated leaf of a span-1 node, R/BvhNode.h:63-67), and its bounding box padded outwards.
-struct SegMedium { double lo[3], hi[3]; uint32_t order, object, twice, pad; };
+//   candidates: the surface leaves whose boxes meet the padded box -- all there is to hit for a ray whose remaining stretch lies inside
+//   the box (a ray scattered inside the medium: a third of all rays of the Book-2 final scene): seg_cand[cand_first .. + cand_count),
+//   each with its position; cand_count = kNone when there are too many of them or one is an instance (such rays then walk the tree).
+struct SegMedium { double lo[3], hi[3]; uint32_t order, object, twice, cand_first, cand_count, pad; };
+struct SegCandidate { uint32_t ref, order; };
+constexpr uint32_t kSegMaxCandidates = 12;
 constexpr uint32_t kSegMaxMedia = 4;
 constexpr uint32_t kSegEnd = 0xFFFFu;  // "to the end of the list" as an upper bound of a segment
 
@@ -182,6 +187,8 @@ struct DeviceScene {
     uint32_t n_fast_nodes;
     const FastOrder *fast_order;    // SCENE_SEGMENTED: parallel to fast_nodes
     const SegMedium *seg_media;     // SCENE_SEGMENTED: the world's medium leaves in visiting order
+    const SegCandidate *seg_cand;   // SCENE_SEGMENTED: candidate leaves of the media (SegMedium::cand_first)
+    uint32_t n_seg_cand;
     uint32_t n_seg_media;
     const TreeNodeRec *tree_nodes;
     const uint32_t *tree_items;   // children of TN_LIST nodes (tree node indices)
@@ -210,7 +217,7 @@ struct DeviceScene {
     // dynamic LDS block, set by the launcher per table; kNone = read the global table.
     uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin, lds_spheres_tab, lds_group_boxes,
         lds_mspheres, lds_msphere_aux, lds_sphere_aux;  // the primitive tables of a sphere world (library-tree kernel, one workgroup per CU)
-    uint32_t lds_fast_order, lds_seg_media;             // segmented walk: both always staged (render.hip launch_one)
+    uint32_t lds_fast_order, lds_seg_media, lds_seg_cand;  // segmented walk: always staged (render.hip launch_one)
     uint32_t flags;
 };
 

@@ -617,6 +617,27 @@ DEV bool object_span(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
     return true;
 }
 
+// The rest of ConstantMedium::Hit (R/ConstantMedium.h:66-93) given its two boundary hits: clip to [tmin, tmax], draw, compare.
+DEV bool medium_draw(double neg_inv_density, uint32_t medium_index, uint32_t oi, const Ray &r, double tmin, double tmax, double t1, double t2,
+                     HitInfo &best, Xorwow &rng)
+{
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0) t1 = 0.0;
+    double ray_len = length(r.d);
+    double inside = (t2 - t1) * ray_len;
+    // log(curand_uniform(..)) has a float argument: the float overload is selected on the reference's
+    // toolchain; evaluated here as the correctly rounded fp32 log.
+    float lg = (float)log((double)xorwow_uniform(rng));
+    double hit_dist = neg_inv_density * (double)lg;
+    if (hit_dist > inside) return false;
+    best.t = t1 + hit_dist / ray_len;
+    best.ref = make_ref(REF_MEDIUM, medium_index);
+    best.obj = oi;
+    return true;
+}
+
 template <class T, int MED = -1>
 DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, HitInfo &best, Xorwow &rng PH_ARG)
 {
@@ -631,37 +652,7 @@ DEV bool object_test(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
         best.obj = oi;
         return true;
     }
-    if (t1 < tmin) t1 = tmin;
-    if (t2 > tmax) t2 = tmax;
-    if (t1 >= t2) return false;
-    if (t1 < 0.0) t1 = 0.0;
-    double ray_len = length(r.d);
-    double inside = (t2 - t1) * ray_len;
-    // log(curand_uniform(..)) has a float argument: the float overload is selected on the reference's
-    // toolchain; evaluated here as the correctly rounded fp32 log.
-    float lg = (float)log((double)xorwow_uniform(rng));
-    double hit_dist = med.neg_inv_density * (double)lg;
-    if (hit_dist > inside) return false;
-    best.t = t1 + hit_dist / ray_len;
-    best.ref = make_ref(REF_MEDIUM, medium_index);
-    best.obj = oi;
-    return true;
-}
-
-// Would ConstantMedium::Hit (R/ConstantMedium.h:52-94) get as far as its draw for this ray with this [tmin, tmax]?  The same
-// boundary queries and the same clipping as object_test, nothing drawn; t_exit = the second boundary hit, unclipped.
-template <class T>
-DEV bool medium_ahead(const DeviceScene &sc, uint32_t oi, const Ray &r, double tmin, double tmax, double &t_exit PH_ARG)
-{
-    bool medium;
-    MediumRec med{};
-    uint32_t medium_index, pref;
-    double t1, t2;
-    if (!object_span<T, 1>(sc, oi, r, tmin, tmax, medium, med, medium_index, t1, t2, pref PH_PASS)) return false;
-    t_exit = t2;
-    if (t1 < tmin) t1 = tmin;
-    if (t2 > tmax) t2 = tmax;
-    return !(t1 >= t2);
+    return medium_draw(med.neg_inv_density, medium_index, oi, r, tmin, tmax, t1, t2, best, rng);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1355,7 +1346,7 @@ DEV void walk_object_pass(const DeviceScene &sc, const NodeView &nv, const Ray &
 //     is left (R/ConstantMedium.h:66-71) -- and both boundary hits lie inside the box.  The reference's call would return
 //     false without a draw, so the medium is skipped and the surfaces on both sides of it are one segment;
 //   * the same when its own boundary queries and clipping, evaluated with the closest hit so far, already say so
-//     (medium_ahead; the closest hit can only come nearer, which clips more);
+//     (object_span + the clipping of R/ConstantMedium.h:66-70; the closest hit can only come nearer, which clips more);
 //   * otherwise the surfaces that precede it are walked first, as far as they can matter (their closest hit is the tMax the
 //     reference calls the medium with), then the medium is tested -- twice where the reference's span-1 node holds it
 //     twice -- with the reference's own arithmetic and draws (object_test);
@@ -1374,27 +1365,89 @@ DEV void seg_advance(const DeviceScene &sc, const Ray &ray, Walk &w, HitInfo &be
             break;
         }
         const SegMedium m = lds_row<SegMedium>(sc.lds_seg_media, stage);
-        double t_exit = 0.0;
+        // its boundary queries (no draw yet): would the call get past its clipping with the closest hit so far?
+        bool is_medium;
+        MediumRec med{};
+        uint32_t medium_index, pref;
+        double t1, t2;
         if (!box_test(m.lo[0], m.hi[0], m.lo[1], m.hi[1], m.lo[2], m.hi[2], ray, w.inv, 0.0, w.closest) ||
-            !medium_ahead<T>(sc, m.object, ray, 0.001, w.closest, t_exit PH_PASS)) {
+            !object_span<T, 1>(sc, m.object, ray, 0.001, w.closest, is_medium, med, medium_index, t1, t2, pref PH_PASS) ||
+            (t1 < 0.001 ? 0.001 : t1) >= (t2 > w.closest ? w.closest : t2)) {
             stage++;  // it would return false before its draw: no medium here for this ray
             continue;
         }
-        if (lo < m.order) {
-            // The surfaces before it first -- but only as far as the medium's far side: the closest hit among them is the tMax
-            // of the medium's call, which clips the far boundary hit to it (t2 = min(t2, tMax)); a hit beyond t_exit changes
-            // nothing there, and the ray's last walk finds it again.
+        // A ray whose stretch that still matters lies inside the medium's box (scattered inside the medium: both ends inside, the box
+        // is convex) can only hit the surface leaves that reach into the box: the host has listed them (SegMedium candidates).
+        auto inside = [&](Vec p) {
+            return p.x >= m.lo[0] && p.x <= m.hi[0] && p.y >= m.lo[1] && p.y <= m.hi[1] && p.z >= m.lo[2] && p.z <= m.hi[2];
+        };
+        const bool local = m.cand_count != kNone && inside(ray.o);
+        // One loop, two trips, so that the candidate tests exist once in the code: trip 0 = the candidates that precede the
+        // medium (only when the walk up to it can be skipped), then the medium's draws; trip 1 = all candidates, when the ray
+        // ends inside the box after the last medium.
+        bool walk_first = false, tested_before = false;
+#pragma nounroll
+        for (int trip = 0; trip < 2; trip++) {
+            const bool here = trip == 0 ? (lo < m.order && local && inside(at(ray, fmin(w.closest, t2))))
+                                        : (stage >= sc.n_seg_media && local && w.any && inside(at(ray, w.closest)));
+            // trip 0: the candidates before the medium; trip 1: the others -- and those of trip 0 again only if that trip did not run
+            // (a leaf answers the same t every time: tested again under a closer bound it can only fall away)
+            const uint32_t from = (trip == 1 && tested_before) ? m.order : 0u, below = trip == 0 ? m.order : kSegEnd;
+            if (here) {
+                for (uint32_t c = 0; c < m.cand_count; c++) {
+                    const SegCandidate cd = lds_row<SegCandidate>(sc.lds_seg_cand, m.cand_first + c);
+                    if (cd.order < from || cd.order >= below) continue;
+                    bool found;
+                    if ((cd.ref >> kRefShift) == REF_BOX) {
+                        // a box: its two corners first, as a slab test a part in 2^30 wider than the box (the six face planes are the
+                        // corner coordinates up to their last bits) -- most candidates end here
+                        const BoxRec bx = get_box(sc, cd.ref & kRefIndexMask);
+                        const double k30 = 9.313225746154785e-10;
+                        const Vec pad = mk(k30 * (fabs(bx.mn[0]) + fabs(bx.mx[0])), k30 * (fabs(bx.mn[1]) + fabs(bx.mx[1])), k30 * (fabs(bx.mn[2]) + fabs(bx.mx[2])));
+                        found = box_test(bx.mn[0] - pad.x, bx.mx[0] + pad.x, bx.mn[1] - pad.y, bx.mx[1] + pad.y, bx.mn[2] - pad.z, bx.mx[2] + pad.z, ray,
+                                         w.inv, 0.0, w.closest);
+                        if (found) {
+                            double t;
+                            uint32_t face = kNone;
+                            found = box_closest(sc, bx, ray, 0.001, w.closest, t, face);
+                            if (found) {
+                                best.t = t;
+                                best.ref = face;
+                                best.obj = kNone;
+                            }
+                        }
+                    } else {
+                        found = leaf_test_kind<T, LK_PRIM>(sc, cd.ref, ray, w.a, 0.001, w.closest, best, rng PH_PASS);
+                    }
+                    if (found) {
+                        w.any = true;
+                        w.closest = best.t;
+                    }
+                }
+                if (trip == 0) tested_before = true;
+                else lo = kSegEnd;  // the candidates were all there is left to hit: no walk
+            }
+            if (trip == 1) break;
+            if (lo < m.order && !here) {
+                // The surfaces before it first -- but only as far as the medium's far side: the closest hit among them is the tMax
+                // of the medium's call, which clips the far boundary hit to it (t2 = min(t2, tMax)); a hit beyond t2 changes
+                // nothing there, and the ray's last walk finds it again.
+                walk_first = true;
+                break;
+            }
+            for (uint32_t c = 0; c <= m.twice; c++)  // the same two boundary hits every time (geometry), the closest hit as it stands
+                if (medium_draw(med.neg_inv_density, medium_index, m.object, ray, 0.001, w.closest, t1, t2, best, rng)) {
+                    w.any = true;
+                    w.closest = best.t;
+                }
+            lo = m.order + 1u;
+            stage++;
+        }
+        if (walk_first) {
             hi = m.order;
-            w.closest = fmin(w.closest, t_exit);
+            w.closest = fmin(w.closest, t2);
             break;
         }
-        for (uint32_t c = 0; c <= m.twice; c++)
-            if (object_test<T, 1>(sc, m.object, ray, 0.001, w.closest, best, rng PH_PASS)) {
-                w.any = true;
-                w.closest = best.t;
-            }
-        lo = m.order + 1u;
-        stage++;
     }
     sg.lo = lo;
     sg.hi = hi;
@@ -2564,7 +2617,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             __builtin_assume(sc.lds_boxes != kNone && sc.lds_objects != kNone && sc.lds_xforms != kNone);
             __builtin_assume(sc.lds_media != kNone && sc.lds_materials != kNone && sc.lds_perlin != kNone);
             __builtin_assume(sc.lds_spheres_tab != kNone && sc.lds_group_boxes != kNone);
-            if constexpr (T::SEG) __builtin_assume(sc.lds_fast_order != kNone && sc.lds_seg_media != kNone);
+            if constexpr (T::SEG) __builtin_assume(sc.lds_fast_order != kNone && sc.lds_seg_media != kNone && sc.lds_seg_cand != kNone);
         }
 #endif
     }
@@ -2605,6 +2658,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             copy(0u, sc.fast_nodes, sc.n_fast_nodes * kFastNodeBytes);
             copy(sc.lds_fast_order, sc.fast_order, sc.n_fast_nodes * (uint32_t)sizeof(FastOrder));
             copy(sc.lds_seg_media, sc.seg_media, sc.n_seg_media * (uint32_t)sizeof(SegMedium));
+            copy(sc.lds_seg_cand, sc.seg_cand, sc.n_seg_cand * (uint32_t)sizeof(SegCandidate));
             nv.n = sc.n_fast_nodes;
         } else if (nv.in_lds) {
             const uint32_t n = sc.n_world_nodes;
@@ -3326,6 +3380,8 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             off += ((size_t)sc.n_fast_nodes * sizeof(FastOrder) + 15) & ~(size_t)15;
             sc.lds_seg_media = (uint32_t)off;
             off += ((size_t)(sc.n_seg_media ? sc.n_seg_media : 1u) * sizeof(SegMedium) + 15) & ~(size_t)15;
+            sc.lds_seg_cand = (uint32_t)off;
+            off += ((size_t)(sc.n_seg_cand ? sc.n_seg_cand : 1u) * sizeof(SegCandidate) + 15) & ~(size_t)15;
             lds = off;
         }
         if (T::COMPOSITE) {

@@ -914,6 +914,7 @@ static void build_segment_tree(FlatScene &f, bool reference_tree_only)
 {
     f.fast_order.clear();
     f.seg_media.clear();
+    f.seg_cand.clear();
     if (reference_tree_only || f.world_kind != WORLD_BVH || !f.fast_nodes.empty()) return;
     const size_t n = f.world_items.size();
     if (n < 4 || n >= kSegEnd || (f.objects.empty() && f.boxes.empty())) return;
@@ -987,6 +988,24 @@ static void build_segment_tree(FlatScene &f, bool reference_tree_only)
         m.twice = 0;
         for (uint32_t nd = 0; nd < f.n_world_nodes; nd++)  // the reference's own tree: a span-1 node holds the leaf twice
             if (f.nodes[nd].a == f.world_items[k] && f.nodes[nd].b == f.world_items[k]) m.twice = 1;
+        // the surface leaves that reach into the padded box (flat_scene.h SegMedium)
+        m.cand_first = (uint32_t)f.seg_cand.size();
+        m.cand_count = 0;
+        for (size_t j = 0; j < refs.size() && m.cand_count != kNone; j++) {
+            const Box &lb = boxes[j];
+            bool meets = true;
+            for (int a = 0; a < 3; a++) meets &= lb.lo[a] <= m.hi[a] && m.lo[a] <= lb.hi[a];
+            if (!meets) continue;
+            const uint32_t tag = refs[j] >> kRefShift;
+            const bool simple = tag == REF_BOX || tag == REF_SPHERE || tag == REF_MSPHERE || tag == REF_QUAD;
+            if (!simple || m.cand_count >= kSegMaxCandidates) {
+                m.cand_count = kNone;
+                f.seg_cand.resize(m.cand_first);
+                break;
+            }
+            f.seg_cand.push_back({refs[j], order_of[j]});
+            m.cand_count++;
+        }
         f.seg_media.push_back(m);
     }
     f.flags |= SCENE_SEGMENTED;

@@ -81,6 +81,7 @@ struct FlatScene {
     std::vector<FastNodeRec> fast_nodes;
     std::vector<FastOrder> fast_order;   // SCENE_SEGMENTED
     std::vector<SegMedium> seg_media;    // SCENE_SEGMENTED
+    std::vector<SegCandidate> seg_cand;  // SCENE_SEGMENTED
     std::vector<uint32_t> world_items;   // leaf refs in final order (both world kinds)
     std::vector<Box> leaf_boxes;         // introspection
     std::vector<int> leaf_kinds;         // introspection: the leaf's kind as constructed (0 sphere, 1 moving sphere, 2 quad, 3 composite)

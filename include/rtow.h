@@ -168,9 +168,10 @@ typedef struct rt_render_params {
     int32_t max_blocks_per_cu;    /* tuning: cap on resident 256-thread workgroups per CU (0 = as many as fit) */
     int32_t pixels_per_wave;      /* list worlds (HittableList worlds and small BVH worlds rendered as lists; no media): pixels a wave works
                                      on at a time, a power of two 1..64; the wave's other lanes share each ray's leaf tests (64 / pixels
-                                     lanes per ray): the same frame bit for bit, a shorter chain per pixel -- what a small frame, or one
-                                     rank's share of a frame, needs.  0 = chosen by the library from the pixels this film owns and the
-                                     lanes the device holds (64 whenever there are pixels enough to fill them) */
+                                     lanes per ray), the same frame bit for bit.  0 or 64 = one lane per ray, which is also the fastest
+                                     setting for every frame size measured (a mixed list's leaves are different
+                                     code, which a group of lanes runs one after the other like a single lane does); smaller values are
+                                     for lists of one kind of leaf and for experiments */
     int32_t reserved0;
 } rt_render_params;
 

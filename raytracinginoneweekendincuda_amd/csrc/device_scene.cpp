@@ -498,23 +498,18 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
     if (prim_bvh_kernel && !roles_in_one_launch && !tune_set("RTOW_PIXEL_CLASSES")) split = false;
     roles_in_one_launch = tune("RTOW_ROLES", roles_in_one_launch ? 1 : 0, 0, 1) != 0;
 
-    // pixels_per_wave.  List scans (and the sphere list when it runs without pixel classes) can give a ray several lanes:
-    // with fewer pixels than the device has lanes -- a small frame, one rank's stripes of a frame -- every pixel's chain
-    // of rays gets shorter by it, and nothing else can shorten the frame (a pixel's samples are one sequential stream).
-    // 0 = automatic: as many pixels per wave as it takes to hand every pixel this film owns to a resident wave at once,
-    // as a power of two; 64 (one lane per ray) as soon as there are pixels enough for every lane.
+    // pixels_per_wave < 64 gives every ray several lanes: the sphere list deals a ray's spheres to the lanes of a group (its
+    // heavy-pixel waves do that by themselves, above), the list-scan kernels a ray's leaves (render.hip scan_leaves_grouped).
+    // 0 = the library's choice, and that is 64 for every frame size measured: a pixel's samples are one sequential chain, a
+    // launch ends with its longest pixel, and the pass of a wave that holds a few rays takes as long as one that holds 64 --
+    // 17.6 us on the Cornell box whether the film owns 640 k pixels or 5 k (1 / 128 of C4: 118 ms for every split from 1 / 8
+    // on) -- while the grouped pass is LONGER, not shorter: the eight leaves of that world are three kinds of code, which a
+    // group of lanes executes one after the other just as one lane does, plus the exchange (C4 / 8: 117 ms at 64 pixels per
+    // wave, 182 at 32, 201 at 16, 324 at 8; profiles/r03_lanes_per_ray.txt).  The parameter stays for worlds of one kind of
+    // leaf and for experiments; the frames are bit-identical either way.
     {
         int ppw = 64;
-        if (p->pixels_per_wave > 0 && p->pixels_per_wave < 64) {
-            ppw = p->pixels_per_wave;
-        } else if (p->pixels_per_wave <= 0 && (list_scan_kernel || (sphere_list_kernel && !split))) {
-            const int vg = f.last_kernel.vgprs > 0 ? f.last_kernel.vgprs : 128;
-            int waves_per_simd = 512 / ((vg + 7) & ~7);
-            waves_per_simd = waves_per_simd < 1 ? 1 : (waves_per_simd > 8 ? 8 : waves_per_simd);
-            const double resident_waves = (double)f.num_cus * 4.0 * waves_per_simd;
-            const double per_wave = (double)f.n_pixels / resident_waves;  // pixels a wave must hold for all to be in flight at once
-            while (ppw > 4 && (double)(ppw / 2) >= per_wave) ppw /= 2;
-        }
+        if (p->pixels_per_wave > 0 && p->pixels_per_wave < 64) ppw = p->pixels_per_wave;
         ppw = tune("RTOW_PIXELS_PER_WAVE", ppw, 1, 64);
         if (list_scan_kernel) {  // the grouped leaf scan deals lanes in powers of two
             int pow2 = 1;

@@ -72,8 +72,18 @@ RTOW_API rt_handle rt_image_texture(rt_scene *s, const unsigned char *rgb, int w
 RTOW_API rt_handle rt_noise_texture(rt_scene *s, double scale, rt_rng *rng);                  /* :153; draws from rng */
 /* What RtwImage::Load does to decoded 8-bit pixels before ImageTexture sees them (R/RtwImage.h:54,66-67,100-105 on top
  * of stbi_loadf's LDR->HDR step, R/external/stb_image.h:1869): out = FloatToByte((float)pow(in / 255.0f, 2.2f)).
- * JPEG decoding itself is the caller's (any decoder; stb's may differ from it by +-1 per byte). in/out may alias. */
+ * For decoded pixels that come from elsewhere (another decoder's output differs from stb's by up to 3 in ~0.6 % of the bytes of
+ * the reference's earthmap.jpg); rt_rtwimage_load below does the whole of RtwImage::Load.  in/out may alias. */
 RTOW_API void rt_rtwimage_bytes(const unsigned char *decoded_srgb, size_t count, unsigned char *out);
+/* RtwImage::Load itself (R/RtwImage.h:51-87 over stbi_loadf, R/StbImageImpl.cpp): read a JPEG file and return the width * height * 3
+ * bytes the reference hands to ImageTexture (row 0 = top), bit for bit what the reference's stb_image build produces for a
+ * sequential Huffman JPEG of 8-bit samples, grey or YCbCr / RGB, any sampling factors, with or without restart intervals
+ * (csrc/jpeg_decode.cpp restates that decoder's inverse DCT, upsampling and colour conversion).  Progressive / arithmetic-coded /
+ * 12-bit / CMYK files return RT_ERR_UNSUPPORTED -- ImageTexture(NULL) then renders the reference's cyan fallback.
+ * rt_jpeg_decode: the 8-bit sRGB pixels only (stbi_load), without RtwImage's linearisation.  Free the result with rt_image_free. */
+RTOW_API int rt_rtwimage_load(const char *path, unsigned char **rgb_out, int *width, int *height);
+RTOW_API int rt_jpeg_decode(const unsigned char *data, size_t size, unsigned char **rgb_out, int *width, int *height);
+RTOW_API void rt_image_free(unsigned char *rgb);
 
 /* ---- materials (R/Material.h, R/Metal.h, R/Dielectric.h) ---- */
 RTOW_API rt_handle rt_lambertian(rt_scene *s, double r, double g, double b);                  /* Material.h:57 */

@@ -19,6 +19,7 @@ from .api import (  # noqa: F401
     write_pfm,
     rtwimage_bytes,
     load_image,
+    jpeg_decode,
     library_path,
     lib,
     FLAG_KEEP_RNG_STATE,

@@ -55,6 +55,9 @@ SIGNATURES = {
     "rt_image_texture": (H, [P, P, I, I]),
     "rt_noise_texture": (H, [P, D, P]),
     "rt_rtwimage_bytes": (None, [P, C.c_size_t, P]),
+    "rt_rtwimage_load": (I, [C.c_char_p, C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
+    "rt_jpeg_decode": (I, [P, C.c_size_t, C.POINTER(P), C.POINTER(I), C.POINTER(I)]),
+    "rt_image_free": (None, [P]),
     "rt_lambertian": (H, [P, D, D, D]),
     "rt_lambertian_tex": (H, [P, H]),
     "rt_metal": (H, [P, D, D, D, D]),

@@ -325,16 +325,29 @@ def rtwimage_bytes(decoded_rgb):
     return out
 
 
-def load_image(path):
-    """Decode an image file with Pillow and apply rtwimage_bytes (R/RtwImage.h:51-87).  Returns None if the
-    file cannot be read, which ImageTexture turns into the reference's cyan fallback."""
+def _take_image(ptr, w, h):
     try:
-        from PIL import Image
-        with Image.open(path) as im:
-            rgb = np.asarray(im.convert("RGB"))
-    except Exception:
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_ubyte)), shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib().rt_image_free(ptr)
+
+
+def jpeg_decode(data):
+    """The 8-bit sRGB pixels (H, W, 3) of a sequential Huffman JPEG exactly as the reference's stb_image decodes them
+    (csrc/jpeg_decode.cpp); raises RtowError for what that restatement does not decode (progressive, CMYK, ...)."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8)
+    ptr, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    _check(lib().rt_jpeg_decode(buf.ctypes.data, buf.size, C.byref(ptr), C.byref(w), C.byref(h)))
+    return _take_image(ptr, w, h)
+
+
+def load_image(path):
+    """RtwImage::Load (R/RtwImage.h:51-87): the bytes the reference hands to ImageTexture for a JPEG file, bit for bit.
+    Returns None if the file cannot be read or decoded, which ImageTexture turns into the reference's cyan fallback."""
+    ptr, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    if lib().rt_rtwimage_load(str(path).encode(), C.byref(ptr), C.byref(w), C.byref(h)) != 0:
         return None
-    return rtwimage_bytes(rgb)
+    return _take_image(ptr, w, h)
 
 
 def stripe_rows(height, stripe, rank, world_size):

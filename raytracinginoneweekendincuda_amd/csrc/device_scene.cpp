@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -240,7 +241,41 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.nodes, d.nodes);
     up(f.fast_nodes, d.fast_nodes);
     up(f.fast_order, d.fast_order);
-    up(f.seg_media, d.seg_media);
+    {
+        // The library tree's rows as the kernels read them: boxes in fp32, outwards (flat_scene.h FastNodeF).  The widening covers
+        // what a conservative fp32 slab test can lose: the rounding of the box, of the ray's origin and of the products, each at
+        // most 2^-23 of the magnitudes involved -- the scene's reach (every leaf box, the media's included: rays start on
+        // surfaces, inside media or at the camera).
+        double reach = 1.0;
+        for (const Box &b : f.leaf_boxes)
+            for (int a = 0; a < 3; a++) reach = std::fmax(reach, std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+        for (int a = 0; a < 3; a++) reach = std::fmax(reach, std::fabs(s.camera.origin[a]) + std::fabs(s.camera.lens_radius) * 2.0);
+        const double widen = reach * 1.9073486328125e-06;  // 2^-19
+        auto down = [](double v) { float x = (float)v; return (double)x > v ? std::nextafterf(x, -INFINITY) : x; };
+        auto up_f = [](double v) { float x = (float)v; return (double)x < v ? std::nextafterf(x, INFINITY) : x; };
+        std::vector<FastNodeF> rows(f.fast_nodes.size());
+        for (size_t k = 0; k < rows.size(); k++) {
+            const FastNodeRec &n = f.fast_nodes[k];
+            FastNodeF &r = rows[k];
+            const double lo[3] = {n.xlo, n.ylo, n.zlo}, hi[3] = {n.xhi, n.yhi, n.zhi};
+            for (int a = 0; a < 3; a++) {
+                r.box[2 * a] = down(lo[a] - widen);
+                r.box[2 * a + 1] = up_f(hi[a] + widen);
+            }
+            r.a = n.a;
+            r.b = n.b;
+            std::memcpy(r.link, n.link, sizeof r.link);
+            r.pad = 0;
+        }
+        up(rows, d.fast_rows);
+        std::vector<SegMedium> media = f.seg_media;
+        for (SegMedium &m : media)
+            for (int a = 0; a < 3; a++) {
+                m.fbox[2 * a] = down(m.lo[a] - widen);
+                m.fbox[2 * a + 1] = up_f(m.hi[a] + widen);
+            }
+        up(media, d.seg_media);
+    }
     up(f.seg_cand, d.seg_cand);
     up(f.world_items, d.world_items);
     up(f.materials, d.materials);

@@ -114,6 +114,12 @@ struct FastNodeRec {
     uint16_t link[8][2];
 };
 constexpr uint32_t kFastEnd = 0xFFFFu;
+// The row as the kernels read it (built at upload time, device_scene.cpp): the box in fp32, rounded OUTWARDS and widened by
+// 2^-19 of the scene's reach.  A node's box only ever prunes -- hits are decided by the leaf tests, in fp64, with the
+// reference's arithmetic -- so a box that is a little too large changes no frame; a conservative fp32 slab test
+// (render.hip box_test_f) then costs half the issue slots of the fp64 one.  68 bytes: 17 words, an odd stride over the
+// LDS banks.  a, b and the links as in FastNodeRec.
+struct FastNodeF { float box[6]; uint32_t a, b; uint16_t link[8][2]; uint32_t pad; };
 constexpr uint32_t kFastBottom = 0x8000u;    // hit link of a bottom node: this bit | kind of its first leaf << 12 (the lane parks there)
 constexpr uint32_t kFastMaxNodes = 0x8000u;  // node indices stay below kFastBottom
 
@@ -131,7 +137,7 @@ struct FastOrder { uint16_t omin, omax, oa, ob; };
 //   candidates: the surface leaves whose boxes meet the padded box -- all there is to hit for a ray whose remaining stretch lies inside
 //   the box (a ray scattered inside the medium: a third of all rays of the Book-2 final scene): seg_cand[cand_first .. + cand_count),
 //   each with its position; cand_count = kNone when there are too many of them or one is an instance (such rays then walk the tree).
-struct SegMedium { double lo[3], hi[3]; uint32_t order, object, twice, cand_first, cand_count, pad; };
+struct SegMedium { double lo[3], hi[3]; uint32_t order, object, twice, cand_first, cand_count, pad; float fbox[6]; };  // fbox: lo/hi as FastNodeF::box
 struct SegCandidate { uint32_t ref, order; };
 constexpr uint32_t kSegMaxCandidates = 12;
 constexpr uint32_t kSegMaxMedia = 4;
@@ -184,6 +190,7 @@ struct DeviceScene {
     const GroupBox *group_boxes;
     const BvhNodeRec *nodes;
     const FastNodeRec *fast_nodes;  // nullptr unless the world has a library tree (see FastNodeRec, FastOrder)
+    const FastNodeF *fast_rows;     // the same nodes as the kernels stage them (FastNodeF)
     uint32_t n_fast_nodes;
     const FastOrder *fast_order;    // SCENE_SEGMENTED: parallel to fast_nodes
     const SegMedium *seg_media;     // SCENE_SEGMENTED: the world's medium leaves in visiting order

@@ -183,11 +183,11 @@ int main(int argc, char **argv)
             std::fprintf(stderr,
                          "usage: rtow [--scene 0..11] [--width W] [--height H] [--spp N] [--depth D] [--seed S]\n"
                          "            [--world bvh|list] [--variant strict|fast] [--device N] [--gpus N] [--output file.ppm]\n"
-                         "            [--earth decoded.ppm | --earth-bytes texture.ppm] [--accelerate-lists] [--flags N]\n"
-                         "  --earth        binary PPM (P6) of earthmap.jpg decoded to 8-bit sRGB by any JPEG decoder; it is linearised and\n"
-                         "                 re-quantised exactly as the reference's RtwImage::Load does.  Decoders differ: libjpeg's (djpeg)\n"
-                         "                 IDCT and chroma upsampling are not stb_image's, so ~0.6 %% of the bytes come out 1-3 off the\n"
-                         "                 reference's and the texture is near-identical, not bit-identical (parity unpinned on that path)\n"
+                         "            [--earth earthmap.jpg|decoded.ppm | --earth-bytes texture.ppm] [--accelerate-lists] [--flags N]\n"
+                         "  --earth        the texture of scenes 2 and 9: a JPEG file (default: ./earthmap.jpg, like the reference) is read as\n"
+                         "                 RtwImage::Load reads it -- decoded as the reference's stb_image decodes it, bit for bit; a binary PPM\n"
+                         "                 (P6) is taken as pixels some other decoder produced (libjpeg's differ from stb's in ~0.6 %% of the\n"
+                         "                 bytes: near-identical texture, parity unpinned) and is linearised and re-quantised the same way\n"
                          "  --earth-bytes  binary PPM (P6) that already holds the bytes RtwImage::Load hands to ImageTexture; with the\n"
                          "                 bytes the reference's own stb_image build decodes (tests/golden/earthmap_stb.npz, written out\n"
                          "                 by tests/golden/make_earth_golden.py) this is the only input that reproduces the reference's\n"
@@ -208,15 +208,29 @@ int main(int argc, char **argv)
     std::vector<unsigned char> earth;
     int earth_w = 0, earth_h = 0;
     if (scene_id == 2 || scene_id == 9) {
-        if (earth_path.empty()) {
-            if (FILE *probe = std::fopen("earthmap.ppm", "rb")) {
-                std::fclose(probe);
-                earth_path = "earthmap.ppm";
-            }
+        if (earth_path.empty()) {  // R/kernel.cu:661: RtwImage::Load("earthmap.jpg") from the working directory
+            for (const char *name : {"earthmap.jpg", "earthmap.ppm"})
+                if (FILE *probe = std::fopen(name, "rb")) {
+                    std::fclose(probe);
+                    earth_path = name;
+                    break;
+                }
         }
+        const bool is_jpeg = earth_path.size() > 4 && (earth_path.rfind(".jpg") == earth_path.size() - 4 || earth_path.rfind(".jpeg") == earth_path.size() - 5 ||
+                                                       earth_path.rfind(".JPG") == earth_path.size() - 4);
         if (earth_path.empty()) {
-            std::fprintf(stderr, "ERROR: Could not load image file 'earthmap.ppm' (pass --earth <decoded earthmap.jpg as P6 PPM>); "
-                                 "the image texture renders cyan.\n");
+            std::fprintf(stderr, "ERROR: Could not load image file 'earthmap.jpg'.\n");  // R/RtwImage.h:57; the texture renders cyan (R/Texture.h:113-114)
+        } else if (is_jpeg) {
+            // the whole of RtwImage::Load (JPEG decode as the reference's stb_image does it, linearisation, FloatToByte)
+            unsigned char *bytes = nullptr;
+            if (rt_rtwimage_load(earth_path.c_str(), &bytes, &earth_w, &earth_h) != RT_OK) {
+                std::fprintf(stderr, "ERROR: Could not load image file '%s' (%s).\n", earth_path.c_str(), rt_last_error());
+                earth_w = earth_h = 0;
+            } else {
+                earth.assign(bytes, bytes + (size_t)earth_w * earth_h * 3);
+                rt_image_free(bytes);
+                std::fprintf(stderr, "Loaded image '%s' (%dx%d) and uploaded to device.\n", earth_path.c_str(), earth_w, earth_h);
+            }
         } else if (!read_p6(earth_path, earth, earth_w, earth_h)) {
             std::fprintf(stderr, "ERROR: Could not load image file '%s'.\n", earth_path.c_str());
             earth.clear();

@@ -928,14 +928,23 @@ struct Walk {
     //           are tested in the next leaf phase;
     //   done    (kNone): the walk is complete (or no walk is in progress).
     uint32_t state;
-    uint32_t oct_off;  // FAST kernels: byte offset, inside a FastNodeRec row, of the link pair of this ray's direction octant
+    uint32_t oct_off;  // library-tree kernels: byte offset, inside a FastNodeF row, of the link pair of this ray's direction octant
+    // library-tree kernels: the ray as the fp32 slab test of their node boxes wants it (box_test_f): 1 / direction and the
+    // origin, in fp32 (`inv` above is then unused: those boxes are never tested in fp64)
+    float ivx, ivy, ivz, cx, cy, cz;  // 1 / direction; origin
     bool any;
 };
 
+template <bool LIBRARY_TREE = false>
 DEV void walk_begin(Walk &w, const Ray &r, double tmax)
 {
-    w.oct_off = 56u + 4u * ((r.d.x < 0.0 ? 1u : 0u) | (r.d.y < 0.0 ? 2u : 0u) | (r.d.z < 0.0 ? 4u : 0u));
-    w.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    w.oct_off = 32u + 4u * ((r.d.x < 0.0 ? 1u : 0u) | (r.d.y < 0.0 ? 2u : 0u) | (r.d.z < 0.0 ? 4u : 0u));
+    if constexpr (LIBRARY_TREE) {
+        w.ivx = 1.0f / (float)r.d.x; w.ivy = 1.0f / (float)r.d.y; w.ivz = 1.0f / (float)r.d.z;
+        w.cx = (float)r.o.x; w.cy = (float)r.o.y; w.cz = (float)r.o.z;
+    } else {
+        w.inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    }
     w.a = dot(r.d, r.d);
     w.closest = tmax;
     w.state = 0;
@@ -1022,9 +1031,34 @@ DEV void walk_leaves(const DeviceScene &sc, const NodeView &nv, const Ray &r, do
     w.state = next;
 }
 
-// ---- the library's own tree (FastNodeRec): same resumable walk, 88-byte rows, links chosen by the ray's octant ----
-constexpr uint32_t kFastNodeBytes = (uint32_t)sizeof(FastNodeRec);
-static_assert(sizeof(FastNodeRec) == 88, "row layout: box 48, leaf refs 8, links 32");
+// ---- the library's own tree (FastNodeF): same resumable walk, 68-byte rows, links chosen by the ray's octant ----
+constexpr uint32_t kFastNodeBytes = (uint32_t)sizeof(FastNodeF);
+static_assert(sizeof(FastNodeF) == 68 && offsetof(FastNodeF, a) == 24 && offsetof(FastNodeF, link) == 32, "row layout: box 24, leaf refs 8, links 32, pad 4");
+// Conservative slab test in fp32.  The boxes of the library's tree only prune: a ray that passes one it should not merely
+// visits a node in vain, a ray that FAILS one it should pass would lose a hit.  So the test may err only towards "hit":
+//   t = (lo - o) * (1/d) like R/AABB.h:77-97, in fp32.  Its error against the exact (lo - o) / d is at most
+//   2^-22 (|lo| + |o|) / |d| (the fp32 copies of o and of 1/d, the subtraction, the product), and the rows are 2^-19 of the
+//   scene's reach (>= |lo|, |o|) wider than the boxes (device_scene.cpp): several times that; the ray's interval
+//   [tmin, closest] is a little wider too.
+// A zero direction component gives infinities, and a NaN where the origin lies in the plane: v_min / v_max drop NaNs, an
+// infinite bound never cuts the interval short on the wrong side -- the behaviour of R/AABB.h:68-98 in fp64.  (The cheaper
+// lo * (1/d) - o * (1/d), one fma per plane, is NOT safe: with 1/d infinite both terms are, and inf - inf or -inf - inf
+// discards or inverts the slab -- measured: 1.6 % of C5's pixels at 5000 spp, from directions with a component exactly 0.)
+DEV bool box_test_f(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, const Walk &w, float tmin, double closest)
+{
+    const float t0x = (xlo - w.cx) * w.ivx, t1x = (xhi - w.cx) * w.ivx;
+    const float t0y = (ylo - w.cy) * w.ivy, t1y = (yhi - w.cy) * w.ivy;
+    const float t0z = (zlo - w.cz) * w.ivz, t1z = (zhi - w.cz) * w.ivz;
+    const float cf = (float)closest * 1.000002f;  // >= closest (round to nearest loses at most 2^-24); +inf stays +inf
+    const float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+    const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), cf));
+    return tfar > tnear;
+}
+DEV bool fast_row_hit(uint32_t base, const Walk &w, double closest)
+{
+    const RT_LDS float *b = (const RT_LDS float *)(lds_raw + base);
+    return box_test_f(b[0], b[1], b[2], b[3], b[4], b[5], w, 0.000999f, closest);  // tmin = 0.001, a little early
+}
 // The rows are only ever read from LDS (the launcher falls back to the reference-tree kernel when they do not fit): a
 // branch between an LDS and a global copy made the compiler merge the two into generic pointers and flat loads.
 [[maybe_unused]] constexpr uint32_t kFastLdsBudget = 60 * 1024;
@@ -1032,11 +1066,8 @@ DEV void walk_node_fast(const Ray &r, double tmin, Walk &w)
 {
     const uint32_t n = w.state;
     const uint32_t base = __umul24(n, kFastNodeBytes);
-    const double xlo = *reinterpret_cast<const double *>(lds_raw + base), xhi = *reinterpret_cast<const double *>(lds_raw + base + 8u);
-    const double ylo = *reinterpret_cast<const double *>(lds_raw + base + 16u), yhi = *reinterpret_cast<const double *>(lds_raw + base + 24u);
-    const double zlo = *reinterpret_cast<const double *>(lds_raw + base + 32u), zhi = *reinterpret_cast<const double *>(lds_raw + base + 40u);
     const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
-    const bool hit = box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
+    const bool hit = fast_row_hit(base, w, w.closest);
     const uint32_t first = links & 0xFFFFu, esc = links >> 16;
     const uint32_t down = (first & kFastBottom) ? (n | kWalkParked) : first;  // a bottom node's hit link says "park here"
     const uint32_t next = esc == kFastEnd ? kNone : esc;
@@ -1049,11 +1080,8 @@ DEV void walk_node_open(const Ray &r, double tmin, Walk &w)
 {
     const uint32_t n = w.state;
     const uint32_t base = __umul24(n, kFastNodeBytes);
-    const double xlo = *reinterpret_cast<const double *>(lds_raw + base), xhi = *reinterpret_cast<const double *>(lds_raw + base + 8u);
-    const double ylo = *reinterpret_cast<const double *>(lds_raw + base + 16u), yhi = *reinterpret_cast<const double *>(lds_raw + base + 24u);
-    const double zlo = *reinterpret_cast<const double *>(lds_raw + base + 32u), zhi = *reinterpret_cast<const double *>(lds_raw + base + 40u);
     const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
-    const bool hit = box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
+    const bool hit = fast_row_hit(base, w, w.closest);
     const uint32_t first = links & 0xFFFFu, esc = links >> 16;
     const uint32_t down = (first & kFastBottom) ? (n | (first << 16)) : first;
     const uint32_t next = esc == kFastEnd ? kNone : esc;
@@ -1063,8 +1091,8 @@ DEV void walk_leaves_fast(const DeviceScene &sc, const Ray &r, double tmin, Walk
 {
     const uint32_t n = w.state & ~kWalkParked;
     const uint32_t base = __umul24(n, kFastNodeBytes);
-    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 48u);
-    const uint32_t nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 52u);
+    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 24u);
+    const uint32_t nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 28u);
     const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
     const uint32_t esc = links >> 16;
     const uint32_t next = esc == kFastEnd ? kNone : esc;
@@ -1113,11 +1141,8 @@ DEV void walk_node_seg(const DeviceScene &sc, const Ray &r, double tmin, Walk &w
 {
     const uint32_t n = w.state;
     const uint32_t base = __umul24(n, kFastNodeBytes);
-    const double xlo = *reinterpret_cast<const double *>(lds_raw + base), xhi = *reinterpret_cast<const double *>(lds_raw + base + 8u);
-    const double ylo = *reinterpret_cast<const double *>(lds_raw + base + 16u), yhi = *reinterpret_cast<const double *>(lds_raw + base + 24u);
-    const double zlo = *reinterpret_cast<const double *>(lds_raw + base + 32u), zhi = *reinterpret_cast<const double *>(lds_raw + base + 40u);
-    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 48u);
-    const uint32_t nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 52u);
+    const uint32_t na = *reinterpret_cast<const uint32_t *>(lds_raw + base + 24u);
+    const uint32_t nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 28u);
     const uint32_t links = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off);
     const uint32_t span = *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_fast_order + n * 8u);        // omin | omax << 16
     const uint32_t leaves = *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_fast_order + n * 8u + 4u);  // oa | ob << 16
@@ -1125,7 +1150,7 @@ DEV void walk_node_seg(const DeviceScene &sc, const Ray &r, double tmin, Walk &w
     const uint32_t oa = leaves & 0xFFFFu, ob = leaves >> 16;
     const bool a_in = oa < hi, b_in = nb != kNone && ob < hi;
     const bool in_range = inner ? (span & 0xFFFFu) < hi : (a_in || b_in);
-    const bool hit = in_range && box_test(xlo, xhi, ylo, yhi, zlo, zhi, r, w.inv, tmin, w.closest);
+    const bool hit = in_range && fast_row_hit(base, w, w.closest);
     const uint32_t first = links & 0xFFFFu, esc = links >> 16;
     const uint32_t pending = a_in ? na : nb;
     const uint32_t park = n | kWalkParked | (a_in ? 0u : kWalkSecond) | (leaf_kind(pending) << kWalkKindShift);
@@ -1135,7 +1160,7 @@ DEV void walk_node_seg(const DeviceScene &sc, const Ray &r, double tmin, Walk &w
 // the pending leaf of a lane parked by walk_node_seg
 DEV uint32_t seg_pending_leaf(uint32_t state)
 {
-    return *reinterpret_cast<const uint32_t *>(lds_raw + __umul24(state & 0x0FFFFFFFu, kFastNodeBytes) + ((state & kWalkSecond) ? 52u : 48u));
+    return *reinterpret_cast<const uint32_t *>(lds_raw + __umul24(state & 0x0FFFFFFFu, kFastNodeBytes) + ((state & kWalkSecond) ? 28u : 24u));
 }
 struct SegState {
     uint32_t lo, hi;  // the walk in progress (or just completed) covers the leaf positions [lo, hi); hi == kSegEnd: the ray's last walk
@@ -1206,7 +1231,7 @@ DEV void walk_leaf_pass(const DeviceScene &sc, const NodeView &nv, const Ray &r,
     [[maybe_unused]] bool b_in = false;  // segmented walk: the node's second leaf lies in the interval being walked
     if constexpr (T::SEG) {
         const uint32_t base = __umul24(n, kFastNodeBytes);
-        nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 52u);
+        nb = *reinterpret_cast<const uint32_t *>(lds_raw + base + 28u);
         const uint32_t esc = *reinterpret_cast<const uint32_t *>(lds_raw + base + w.oct_off) >> 16;
         next = esc == kFastEnd ? kNone : esc;
         const uint32_t ob = *reinterpret_cast<const uint32_t *>(lds_raw + sc.lds_fast_order + n * 8u + 4u) >> 16;
@@ -1370,7 +1395,7 @@ DEV void seg_advance(const DeviceScene &sc, const Ray &ray, Walk &w, HitInfo &be
         MediumRec med{};
         uint32_t medium_index, pref;
         double t1, t2;
-        if (!box_test(m.lo[0], m.hi[0], m.lo[1], m.hi[1], m.lo[2], m.hi[2], ray, w.inv, 0.0, w.closest) ||
+        if (!box_test_f(m.fbox[0], m.fbox[1], m.fbox[2], m.fbox[3], m.fbox[4], m.fbox[5], w, 0.0f, w.closest) ||
             !object_span<T, 1>(sc, m.object, ray, 0.001, w.closest, is_medium, med, medium_index, t1, t2, pref PH_PASS) ||
             (t1 < 0.001 ? 0.001 : t1) >= (t2 > w.closest ? w.closest : t2)) {
             stage++;  // it would return false before its draw: no medium here for this ray
@@ -1405,7 +1430,7 @@ DEV void seg_advance(const DeviceScene &sc, const Ray &ray, Walk &w, HitInfo &be
                         const double k30 = 9.313225746154785e-10;
                         const Vec pad = mk(k30 * (fabs(bx.mn[0]) + fabs(bx.mx[0])), k30 * (fabs(bx.mn[1]) + fabs(bx.mx[1])), k30 * (fabs(bx.mn[2]) + fabs(bx.mx[2])));
                         found = box_test(bx.mn[0] - pad.x, bx.mx[0] + pad.x, bx.mn[1] - pad.y, bx.mx[1] + pad.y, bx.mn[2] - pad.z, bx.mx[2] + pad.z, ray,
-                                         w.inv, 0.0, w.closest);
+                                         mk(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z), 0.0, w.closest);
                         if (found) {
                             double t;
                             uint32_t face = kNone;
@@ -2632,7 +2657,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             {  // the library's own tree: rows copied as they are (always staged: see walk_node_fast)
                 const uint32_t words = sc.n_fast_nodes * (kFastNodeBytes / 4u);
                 uint32_t *dst = reinterpret_cast<uint32_t *>(lds_raw);
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.fast_nodes);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.fast_rows);
                 for (uint32_t k = threadIdx.x; k < words; k += blockDim.x) dst[k] = src[k];
                 nv.n = sc.n_fast_nodes;
                 auto stage = [](uint32_t off, const void *table, uint32_t bytes) {
@@ -2655,7 +2680,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                 const uint32_t *src = static_cast<const uint32_t *>(table);
                 for (uint32_t w = threadIdx.x; w < bytes / 4u; w += blockDim.x) dst[w] = src[w];
             };
-            copy(0u, sc.fast_nodes, sc.n_fast_nodes * kFastNodeBytes);
+            copy(0u, sc.fast_rows, sc.n_fast_nodes * kFastNodeBytes);
             copy(sc.lds_fast_order, sc.fast_order, sc.n_fast_nodes * (uint32_t)sizeof(FastOrder));
             copy(sc.lds_seg_media, sc.seg_media, sc.n_seg_media * (uint32_t)sizeof(SegMedium));
             copy(sc.lds_seg_cand, sc.seg_cand, sc.n_seg_cand * (uint32_t)sizeof(SegCandidate));
@@ -2845,7 +2870,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                         ray = camera_ray(cam, i, j, a.width, a.height, rng);
                         active = true;
                         if constexpr (T::WORLD == 0) {
-                            walk_begin(walk, ray, DBL_MAX);
+                            walk_begin<T::FAST || T::SEG>(walk, ray, DBL_MAX);
                             if constexpr (T::SEG) {  // "between walks", before the first one: seg_advance at the head of the next round
                                 seg = SegState{0u, 0u, 0u};
                                 walk.state = kNone;
@@ -3115,7 +3140,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #endif
             if constexpr (T::WORLD == 0) {
                 if (active) {
-                    walk_begin(walk, ray, DBL_MAX);
+                    walk_begin<T::FAST || T::SEG>(walk, ray, DBL_MAX);
                     if constexpr (T::SEG) {
                         seg = SegState{0u, 0u, 0u};
                         walk.state = kNone;

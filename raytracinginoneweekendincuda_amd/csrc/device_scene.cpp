@@ -509,10 +509,14 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
     // Every pixel is still rendered exactly once from its own stream: the frame is the same bit for bit
     // (tests: ...tile_ranking..., ...heavy_and_light...; RT_FLAG_ROW_MAJOR_TILES / RT_FLAG_NO_PIXEL_CLASSES turn them off).
     const bool bvh_kernel = kind < 8;
-    bool rank_tiles = bvh_kernel && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 && !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
-    rank_tiles = rank_tiles && tune("RTOW_TILE_SORT", 1, 0, 1) != 0;
     const bool sphere_list_kernel = kind >= 16 && kind < 32, prim_bvh_kernel = kind == 0;
     const bool list_scan_kernel = kind == 8 || kind == 10;  // list scans without media: leaves can be dealt to lanes (render.hip scan_leaves_grouped)
+    //  * list worlds too (r3): a frame is a few "generations" of pixels per lane (C4: 640 k pixels on 262 k lanes), and the last
+    //    generation lasts as long as its longest pixel while ever fewer lanes are busy (C4: queue dry at 148 ms, last wave out
+    //    at 261).  Heaviest tiles first makes the pixels that start last the cheap ones.
+    bool rank_tiles = (bvh_kernel || list_scan_kernel || sphere_list_kernel) && p->samples_per_pixel >= 32 && f.n_tiles >= 1024 &&
+                      !(p->flags & RT_FLAG_ROW_MAJOR_TILES);
+    rank_tiles = rank_tiles && tune("RTOW_TILE_SORT", 1, 0, 1) != 0;
     // the deep general kernel (one 768-thread workgroup per CU, C5): its ray chains are the longest of all (a ray takes ~140 us
     // in a full wave), which decides the frame whenever a GPU holds few pixels per lane -- a small frame, or one rank's share
     const bool deep_kernel = kind == 7 && f.last_kernel.lds_bytes > 64 * 1024;
@@ -583,7 +587,10 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
         if (rank_tiles) HIP_TRY(hipMemsetAsync(f.tile_cost, 0, f.n_tiles * sizeof(uint32_t), stream));
         HIP_TRY(p->variant ? launch_render_fast(ds, probe, stream) : launch_render_strict(ds, probe, stream));
         if (rank_tiles) {
-            HIP_TRY(launch_tile_order(f.tile_cost, f.tile_order, f.n_tiles, stream));
+            // the order is kept row-major only where the heaviest tile is within an eighth of the mean (r3: was x4, which sorted for
+            // glass only; C3 +1.7 % with every spread sorted, C2 / C5 indifferent between 9 / 8 and 32 / 8, one call)
+            const uint32_t flat_x8 = (uint32_t)tune("RTOW_TILE_FLAT_X8", 9, 8, 1 << 20);
+            HIP_TRY(launch_tile_order(f.tile_cost, f.tile_order, f.n_tiles, flat_x8, stream));
             ra.tile_order = f.tile_order;
         }
         HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, (light) queue cursor

@@ -3194,7 +3194,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #if RT_STRICT && RT_GROUP == 0
 // Rank the tiles by probed cost, heaviest first.  A pixel's samples are sequential (one RNG stream), so the frame can
 // never end before its longest pixel does: those pixels have to start first, not wherever row-major order puts them.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, uint32_t *order, uint32_t n)
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, uint32_t *order, uint32_t n, uint32_t flat_x8)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t peak;
@@ -3215,8 +3215,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, 
     atomicAdd(&total, sum);
     __syncthreads();
     const uint32_t top = peak;
-    // Nothing to gain where no tile stands out (Cornell box: every path is short): keep the row-major order.
-    if ((unsigned long long)top * n <= 4ull * total) {
+    // Nothing to gain where no tile stands out: keep the row-major order.  flat_x8 / 8 = how far the heaviest tile must be above
+    // the mean for the order to matter (launcher's choice: 4 where only the longest chains count, less where the spread of
+    // ordinary tiles decides the last generation of pixels, see rt_render_launch).
+    if ((unsigned long long)top * n * 8ull <= (unsigned long long)flat_x8 * total) {
         for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) order[k] = k;
         return;
     }
@@ -3254,10 +3256,10 @@ hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, u
     return hipGetLastError();
 }
 
-hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, hipStream_t stream)
+hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, uint32_t flat_x8, hipStream_t stream)
 {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, tile_order, n_tiles);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, tile_cost, tile_order, n_tiles, flat_x8);
     return hipGetLastError();
 }
 #endif

@@ -92,6 +92,7 @@ hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, u
                                   uint32_t *count, hipStream_t stream);
 
 // tile_order[k] = the tile with the k-th highest cost (counting sort over 256 cost classes; one workgroup)
-hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, hipStream_t stream);
+// (flat_x8 / 8 = ratio of the heaviest tile to the mean below which the row-major order is kept)
+hipError_t launch_tile_order(const uint32_t *tile_cost, uint32_t *tile_order, uint32_t n_tiles, uint32_t flat_x8, hipStream_t stream);
 
 } // namespace rtow

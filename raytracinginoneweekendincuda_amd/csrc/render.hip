@@ -2784,7 +2784,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     [[maybe_unused]] SegState seg{0u, kSegEnd, 0u};  // segmented walk: hi == kSegEnd also means "nothing more to walk" for an idle lane
 
 #if RT_STAMP
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicMin(a.ray_counter + 5, (unsigned long long)wall_clock64());
+    if (threadIdx.x == 0 && blockIdx.x == 0 && !a.probe) atomicMin(a.ray_counter + 5, (unsigned long long)wall_clock64());
 #endif
 #if RT_PHASES
     PhaseSums ph{};
@@ -2829,7 +2829,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                     else exhausted = true;
                 }
 #if RT_STAMP
-                if (exhausted && lane == 0) atomicMin(a.ray_counter + 2, (unsigned long long)wall_clock64());
+                if (exhausted && lane == 0 && !a.probe) atomicMin(a.ray_counter + 2, (unsigned long long)wall_clock64());
 #endif
                 const uint32_t slot = base + (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                 if (((need >> lane) & 1ull) && slot < queue_len) {
@@ -3180,7 +3180,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #endif
 
 #if RT_STAMP
-    if (lane == 0) {
+    if (lane == 0 && !a.probe) {
         atomicMax(a.ray_counter + 3, (unsigned long long)wall_clock64());
         atomicMin(a.ray_counter + 4, (unsigned long long)wall_clock64());  // first wave to finish
     }

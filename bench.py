@@ -130,7 +130,21 @@ def committed_pmc(workload, spp, variant):
     return None, None
 
 
-def roofline_of(workload, world_kind, spp, variant, flags, stats, rays, kernel_s):
+def committed_executed(workload, kernel_kind, variant):
+    """Executed fp64-slot count per ray of a kernel that does not make the reference's element tests one for one, as measured with
+    the RT_PHASES build and committed (profiles/rNN_<workload>_executed.json); None when there is none for this kernel."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_executed.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel_kind") == kernel_kind and d.get("variant") == variant and "slots_per_ray_executed" in d:
+            return d, os.path.relpath(path, ROOT)
+    return None
+
+
+def roofline_of(workload, world_kind, spp, variant, flags, stats, rays, kernel_s, kernel_kind=-1):
     """The `roofline` object: scalars only, so that a record which keeps one level of the line keeps all of it.
     `frac` counts the fp64 VALU slots the kernel EXECUTES (sphere-list kernel: the 8-instruction filter, not the reference's
     13-instruction discriminant); `frac_reference_arithmetic` counts the reference's arithmetic for the same element tests."""
@@ -147,6 +161,13 @@ def roofline_of(workload, world_kind, spp, variant, flags, stats, rays, kernel_s
         executed_note = ("every sphere of the list goes through the 8-instruction conservative filter (13 for the reference's "
                          "discriminant and compare), the few survivors per ray through the reference's test")
     ex_per_ray = sum(ex[k] * stats[k] for k in ex) / n_rays
+    executed_src = "slot table x oracle-counted element tests"
+    measured = committed_executed(workload, kernel_kind, variant)
+    if measured is not None:   # kernels that do not make the reference's element tests one for one (library tree, segmented walk)
+        ex_per_ray = measured[0]["slots_per_ray_executed"]
+        executed_src = measured[1]
+        executed_note = ("the kernel walks the library's tree, not the reference's: its node visits and leaf tests per ray were counted "
+                         "with the RT_PHASES build (" + measured[1] + "), fp32 slab tests at half an fp64 slot per operation")
     bytes_per_ray = sum(BYTES[k] * stats[k] for k in BYTES) / n_rays
     rays_per_s = float(rays) / kernel_s
     pmc, pmc_src = committed_pmc(workload, spp, variant)
@@ -160,7 +181,7 @@ def roofline_of(workload, world_kind, spp, variant, flags, stats, rays, kernel_s
         "bound": "valu_fp64", "unit": "TFLOP/s", "peak": FP64_VECTOR_PEAK_TFLOPS,
         "achieved": ex_per_ray * rays_per_s * 2 * 1e-12,       # issue-slot equivalent: the peak counts every slot as an FMA (2 flop)
         "frac": ex_per_ray * rays_per_s / PEAK_SLOTS_PER_S,
-        "slots_per_ray": ex_per_ray,
+        "slots_per_ray": ex_per_ray, "executed_source": executed_src,
         "frac_reference_arithmetic": ref_per_ray * rays_per_s / PEAK_SLOTS_PER_S,
         "achieved_reference_arithmetic": ref_per_ray * rays_per_s * 2 * 1e-12,
         "slots_per_ray_reference_arithmetic": ref_per_ray,
@@ -526,7 +547,7 @@ def main():
             par["other_variant"] = "strict" if other_variant == 0 else "fast"
             out["parity"] = par
             # ---- roofline: fp64 VALU issue slots (the limiter); the contract's HBM algorithmic figure beside it ----
-            out["roofline"] = roofline_of(args.workload, world_kind, spp, args.variant, args.flags, stats, float(st.rays), kernel_avg)
+            out["roofline"] = roofline_of(args.workload, world_kind, spp, args.variant, args.flags, stats, float(st.rays), kernel_avg, int(st.kernel_kind))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -716,7 +716,7 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         if (tune_set("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;
             const char *name[24] = {"node step", "leaf test", "shade", "refill", "  group/instance", "  medium", "  primitive", "",
-                                    "    record+xforms", "    box", "    sub-BVH", "    other geometry", "between walks again", "limited node pass", "", "",
+                                    "    record+xforms", "    box", "    sub-BVH", "    other geometry", "between walks again", "limited node pass", "node visits (lanes)", "",
                                     "box pass", "medium pass / between walks", "object pass", "primitive pass", "  hit record", "  scatter",
                                     "  next camera ray", "  pixel done"};
             if ((f.last_kernel.kind & 63) >= 16) {  // sphere-list kernel: slots 0 / 1 are its two scans

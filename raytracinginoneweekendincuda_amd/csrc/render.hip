@@ -414,6 +414,8 @@ struct PhaseSums {
 #define PH_ARG , PhaseSums &ph
 #define PH_PASS , ph
 #define PH_SUB_BEGIN() const unsigned long long ph_s0 = __builtin_readcyclecounter()
+// per-lane event counts (summed over the wave at the end like the per-lane time shares): slot 14 = node visits
+#define PH_COUNT(k) do { ph.l[k] += 1024ull; ph.n[k] += 1024ull; } while (0)
 // inside divergent control flow the sums are per lane: each lane books its share (x1024), the wave adds them up at the end
 #define PH_SUB_END(k)                                                                              \
     do {                                                                                           \
@@ -428,6 +430,7 @@ struct PhaseSums {
 #define PH_ARG
 #define PH_PASS
 #define PH_SUB_BEGIN() do { } while (0)
+#define PH_COUNT(k) do { } while (0)
 #define PH_SUB_END(k) do { } while (0)
 #endif
 // Ray into the object space of a composite leaf: Translate (R/Instance.h:46) and RotateY (:121-131)
@@ -2972,26 +2975,44 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                         if (mover) {
                             if constexpr (T::FAST) {
                                 walk_node_fast(ray, 0.001, walk);
-                                if (walk_moving(walk.state)) walk_node_fast(ray, 0.001, walk);
+                                PH_COUNT(14);
+                                if (walk_moving(walk.state)) {
+                                    walk_node_fast(ray, 0.001, walk);
+                                    PH_COUNT(14);
+                                }
 #if RT_FAST_VISITS >= 3
                                 if (walk_moving(walk.state)) walk_node_fast(ray, 0.001, walk);
 #endif
                             } else if constexpr (T::SEG) {
                                 if (limited_walks) {  // some lane of the wave is on its way to a medium (wave-uniform, rare)
                                     walk_node_seg(sc, ray, 0.001, walk, seg.hi);
-                                    if (walk_moving(walk.state)) walk_node_seg(sc, ray, 0.001, walk, seg.hi);
+                                    PH_COUNT(14);
+                                    if (walk_moving(walk.state)) {
+                                        walk_node_seg(sc, ray, 0.001, walk, seg.hi);
+                                        PH_COUNT(14);
+                                    }
                                 } else {
                                     walk_node_open(ray, 0.001, walk);
-                                    if (walk_moving(walk.state)) walk_node_open(ray, 0.001, walk);
+                                    PH_COUNT(14);
+                                    if (walk_moving(walk.state)) {
+                                        walk_node_open(ray, 0.001, walk);
+                                        PH_COUNT(14);
+                                    }
                                 }
                             } else
-                            walk_node<T::BATCH>(nv, ray, 0.001, walk);
+                            {
+                                walk_node<T::BATCH>(nv, ray, 0.001, walk);
+                                PH_COUNT(14);
+                            }
                             // Primitive worlds (deep BVH, cheap leaves): a second visit before the next look at the
                             // wave's state -- the ballots and counts that steer the phases cost a fifth of a node visit.
                             // Not for composite worlds: the Cornell box's tree is three levels deep (measured -17 %).
                             // Kind-batched kernels run on deep trees too: the same second visit (C5 +x %).
                             if constexpr ((!T::COMPOSITE || T::BATCH) && !T::FAST && !T::SEG) {
-                                if (walk_moving(walk.state)) walk_node<T::BATCH>(nv, ray, 0.001, walk);
+                                if (walk_moving(walk.state)) {
+                                    walk_node<T::BATCH>(nv, ray, 0.001, walk);
+                                    PH_COUNT(14);
+                                }
                             }
                         }
                         PH_END(0, mover);
@@ -3159,7 +3180,8 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #endif
     }
 #if RT_PHASES
-    for (int k = 4; k < 12; k++) {
+    for (int k = 4; k < 15; k++) {
+        if (k == 12 || k == 13) continue;  // wave-level slots
         for (int off = 32; off > 0; off >>= 1) {
             ph.t[k] += __shfl_down(ph.t[k], off, 64);
             ph.l[k] += __shfl_down(ph.l[k], off, 64);

@@ -58,7 +58,9 @@ BYTES = {"box_tests": 56, "sphere_tests": 36, "msphere_tests": 76, "quad_tests":
 SLOTS = {"box_tests": 25, "sphere_tests": 13, "msphere_tests": 16, "quad_tests": 19, "xform_entries": 6,
          "medium_draws": 45, "scatters": 40, "noise_calls": 140, "rays": 58}
 SLOTS_LIST_WORLD_RAY = 28     # list worlds need no 1/d per ray
-SLOTS_FILTERED_SPHERE = 8     # what the sphere-list kernel executes per sphere: the conservative filter (render.hip filter_four)
+SLOTS_FILTERED_SPHERE = 4.5   # what the sphere-list kernel executes per sphere: the conservative filter in packed fp32, 7 v_pk_* + 2 compares per
+                              # PAIR of spheres (render.hip filter_pairs; each issues in the slot of one fp64 instruction)
+SLOTS_FILTERED_SPHERE_FP64 = 8  # ... and its fp64 form, one sphere at a time (RT_FLAG_FILTER_FP64; render.hip filter_four)
 SLOTS_FILTER_SETUP = 60       # and per ray: 1/|d| (sqrt + divide), foot point, thresholds
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the 157.3 TF fp32 vector rate: one wave64 fp64 instruction per 4 cycles per SIMD
@@ -156,10 +158,11 @@ def roofline_of(workload, world_kind, spp, variant, flags, stats, rays, kernel_s
     ex = dict(slots)
     executed_note = "the kernel executes the reference's arithmetic for every element test it makes"
     if workload == "c2" and not (flags & 256):
-        ex["sphere_tests"] = SLOTS_FILTERED_SPHERE
+        ex["sphere_tests"] = SLOTS_FILTERED_SPHERE_FP64 if (flags & 2048) else SLOTS_FILTERED_SPHERE
         ex["rays"] = slots["rays"] + SLOTS_FILTER_SETUP
-        executed_note = ("every sphere of the list goes through the 8-instruction conservative filter (13 for the reference's "
-                         "discriminant and compare), the few survivors per ray through the reference's test")
+        executed_note = ("every sphere of the list goes through the conservative filter -- 9 instructions per two spheres in packed fp32 "
+                         "(8 per sphere in fp64 with RT_FLAG_FILTER_FP64; 13 for the reference's discriminant and compare) -- the few "
+                         "survivors per ray through the reference's test")
     ex_per_ray = sum(ex[k] * stats[k] for k in ex) / n_rays
     executed_src = "slot table x oracle-counted element tests"
     measured = committed_executed(workload, kernel_kind, variant)

@@ -204,6 +204,9 @@ typedef struct rt_render_params {
 #define RT_FLAG_EXACT_SCAN 256u      /* sphere-list worlds: every ray runs the reference's discriminant against every sphere (default: a cheaper
                                       conservative filter rejects the spheres a ray's line misses and only the survivors go through the
                                       reference's arithmetic; the image is the same bit for bit either way) */
+#define RT_FLAG_FILTER_FP64 2048u     /* sphere-list worlds: the conservative filter in fp64, one sphere per 8 instructions (default: its packed
+                                      fp32 form, two spheres per 9 instructions, a little coarser; the survivors always go through the
+                                      reference's fp64 test, so the image is the same bit for bit) -- tests, timing */
 #define RT_FLAG_ACCELERATE_LISTS 512u /* HittableList worlds of primitives only (no leaf draws random numbers): render through the library's
                                       own tree as a BvhNode world would be -- the reference's "BVH image == list image" invariant the other
                                       way round; off by default so that a list world is scanned as the reference scans it.  Ignored for

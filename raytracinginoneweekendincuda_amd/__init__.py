@@ -27,7 +27,7 @@ from .api import (  # noqa: F401
     FLAG_OVERDUE_PRIORITY,
     FLAG_ACCUMULATE,
     FLAG_ROW_MAJOR_TILES,
-    FLAG_ALWAYS_WALK, FLAG_NO_PIXEL_CLASSES, FLAG_REFERENCE_TREE, FLAG_EXACT_SCAN, FLAG_ACCELERATE_LISTS, FLAG_COOP_SINGLE,
+    FLAG_ALWAYS_WALK, FLAG_NO_PIXEL_CLASSES, FLAG_REFERENCE_TREE, FLAG_EXACT_SCAN, FLAG_ACCELERATE_LISTS, FLAG_COOP_SINGLE, FLAG_FILTER_FP64,
     SCENE_PLAIN_QUADS, SCENE_REFERENCE_TREE_ONLY,
 )
 

@@ -28,6 +28,7 @@ FLAG_ALWAYS_WALK = 32       # small BVH worlds: walk the tree instead of scannin
 FLAG_ACCELERATE_LISTS = 512  # list worlds of primitives: render through the library's tree (default: scan the list as the reference does)
 FLAG_EXACT_SCAN = 256       # sphere-list worlds: the reference's discriminant for every sphere (default: conservative filter first)
 FLAG_REFERENCE_TREE = 128   # primitive BVH worlds: walk the reference's own tree (default: the library's SAH tree)
+FLAG_FILTER_FP64 = 2048     # sphere-list worlds: the fp64 filter instead of its packed fp32 form (tests, timing)
 FLAG_COOP_SINGLE = 1024     # tests: sphere-list worlds, thin waves scan one ray at a time (the older scheme)
 FLAG_NO_PIXEL_CLASSES = 64  # sphere-list worlds: one launch for all pixels (no separate launch for the long-chain pixels)
 

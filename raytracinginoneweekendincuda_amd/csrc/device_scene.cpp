@@ -222,6 +222,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     };
     up(f.spheres, d.spheres);
     up(f.sphere_scan, d.sphere_scan);
+    up(f.sphere_scan32, d.sphere_scan32);
     up(f.sphere_aux, d.sphere_aux);
     up(f.mspheres, d.mspheres);
     up(f.ms_planes, d.ms_planes);
@@ -296,6 +297,7 @@ int rt_scene_upload(rt_scene *scene, int device)
     d.scan_cost = f.scan_cost;
     d.n_spheres = (uint32_t)f.spheres.size();
     d.scan_reach = f.scan_reach;
+    d.scan_reach32 = f.scan_reach32;
     d.n_mspheres = (uint32_t)f.mspheres.size();
     d.n_quads = (uint32_t)f.quads.size();
     d.n_objects = (uint32_t)f.objects.size();
@@ -486,6 +488,7 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
     ra.reference_tree = (p->flags & RT_FLAG_REFERENCE_TREE) ? 1 : 0;
     ra.exact_scan = tune("RTOW_EXACT_SCAN", (p->flags & RT_FLAG_EXACT_SCAN) ? 1 : 0, 0, 1);
     ra.accelerate_lists = (p->flags & RT_FLAG_ACCELERATE_LISTS) ? 1 : 0;
+    ra.filter_fp64 = tune("RTOW_FILTER_FP64", (p->flags & RT_FLAG_FILTER_FP64) ? 1 : 0, 0, 1);
     ra.heavy_scan = tune("RTOW_HEAVY_SCAN", 0, 0, 1);
     ra.small_world = tune("RTOW_SMALL_WORLD", 64, 0, 1 << 20);  // scan budget in half sphere tests, see FlatScene::scan_cost
     const DeviceScene &ds = s.device[f.device]->scene;

@@ -31,6 +31,12 @@ static inline constexpr uint32_t make_ref(uint32_t tag, uint32_t index) { return
 struct SphereGeom { double cx, cy, cz, r2; };            // r2 = radius * radius
 // The same sphere as the conservative filter of the list scan reads it (render.hip filter_four): k = |c|^2 - r^2.
 struct SphereScanRow { double cx, cy, cz, k; };
+// Two spheres of the list as the PACKED fp32 form of that filter reads them (render.hip filter_pairs): gfx950 issues a
+// v_pk_fma_f32 -- two fp32 fmas per lane -- in the slot of one fp64 fma, so a conservative fp32 filter over pairs of spheres
+// costs 9 instructions per TWO spheres where the fp64 one costs 8 per sphere.  k = fl32(|c|^2 - r^2); -inf = "always passes"
+// (a sphere beyond the reach the fp32 margin is sized for, e.g. the ground sphere of radius 1000, or a non-finite row);
+// +inf = padding of an odd count.
+struct SphereScanPair { float cx[2], cy[2], cz[2], k[2]; };
 struct SphereAux { double inv_r; uint32_t mat; uint32_t pad; };
 
 // MovingSphere (R/MovingSphere.h:19-36): centre(t) = c0 + ((t - t0) / dt) * dc
@@ -176,6 +182,8 @@ struct DeviceScene {
     const SphereGeom *spheres;
     const SphereScanRow *sphere_scan;  // parallel to spheres
     double scan_reach;                 // max over spheres of |centre| + radius (bounds the filter's rounding error)
+    const SphereScanPair *sphere_scan32;  // pairs (2 i, 2 i + 1) of the same list
+    double scan_reach32;               // max of |centre| + radius over the spheres the fp32 filter decides (the others always pass)
     const SphereAux *sphere_aux;
     const MSphereGeom *mspheres;
     const SphereAux *msphere_aux;

@@ -1723,6 +1723,133 @@ DEV void drain_filtered(const SphereGeom *__restrict__ spheres, uint32_t planes_
     count = 0;
 }
 
+// ---- the same filter in packed fp32, two spheres per instruction (r3) -------------------------------------------------------
+// gfx950 issues v_pk_fma_f32 (two fp32 fmas per lane) in the slot of one v_fma_f64, so the filter's seven multiply-adds cost
+// 7 instructions per PAIR of spheres plus two compares: 4.5 per sphere instead of 8.  It only ever rejects, so it may be as
+// coarse as fp32 makes it as long as it never rejects what the reference accepts.  Error of the computed Q against the exact
+// disc / a + K + M (same quantities as above, everything rounded to fp32 -- centre, u, 2p, the per-ray addend, every product
+// and sum): at most 2^-24 (17 W^2 + 5 M) with W = |o| + max |C| over the spheres this filter DECIDES (`scan_reach32`: the bulk
+// of the list; a sphere far outside it, like the Book-1 ground sphere, has k = -inf and always goes on to the exact test),
+// plus 2^-24 W^2 for the rounding of K.  With M = 2^-18 W^2 (64 x 2^-24 W^2) the threshold is lowered 3.5 times that:
+// a sphere the reference could accept always passes; a sphere is passed in vain by rays that miss it by less than
+// M / 2r (C2: W = 30, M = 3.4e-3, 4 % of a small sphere's radius).  The behind-the-origin shortcut keeps its form with
+// the fp32 margins (bu > 2^-9 W >> its own error 2^-21 W; bu^2 - disc/a > M).  tests/test_filter_margin.py restates both
+// forms operation by operation.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct ScanRay32 {
+    float ux, uy, uz, px, py, pz;  // d / |d|,  2 (o - (o.u) u)
+    float nthr;                    // M - (o.o - (o.u)^2)
+    float od, root_m;              // o.u,  sqrt(M)
+};
+DEV ScanRay32 scan_ray32(const Ray &r, double a, double reach)
+{
+    ScanRay32 f;
+    const double oo = dot(r.o, r.o);
+    const double w = sqrt(oo) + reach;
+    const bool sane = a > 1e-280 && a < 1e280 && w < 1e15;
+    if (sane) {
+        const double inv = 1.0 / sqrt(a);
+        const Vec u = inv * r.d;
+        const double od = dot(r.o, u);
+        const Vec p2 = 2.0 * (r.o - od * u);
+        const double root_m = 0x1p-9 * w;
+        f.ux = (float)u.x; f.uy = (float)u.y; f.uz = (float)u.z;
+        f.px = (float)p2.x; f.py = (float)p2.y; f.pz = (float)p2.z;
+        f.od = (float)od;
+        f.root_m = (float)root_m;
+        f.nthr = (float)(root_m * root_m - (oo - od * od));
+    } else {  // a degenerate ray passes every sphere and none is called behind
+        f.ux = f.uy = f.uz = f.px = f.py = f.pz = f.od = 0.0f;
+        f.root_m = __builtin_inff();
+        f.nthr = __builtin_inff();
+    }
+    return f;
+}
+DEV SphereScanPair load_scan_pair(const SphereScanPair *table, uint32_t k)
+{
+    const RT_CONST float *p = (const RT_CONST float *)(uintptr_t)(table + k);
+    return SphereScanPair{{p[0], p[1]}, {p[2], p[3]}, {p[4], p[5]}, {p[6], p[7]}};
+}
+DEV void scan_pairs_arrived(const SphereScanPair &g0, const SphereScanPair &g1)
+{
+    asm volatile("" ::"s"(g0.cx[0]), "s"(g0.cx[1]), "s"(g0.cy[0]), "s"(g0.cy[1]), "s"(g0.cz[0]), "s"(g0.cz[1]), "s"(g0.k[0]), "s"(g0.k[1]));
+    asm volatile("" ::"s"(g1.cx[0]), "s"(g1.cx[1]), "s"(g1.cy[0]), "s"(g1.cy[1]), "s"(g1.cz[0]), "s"(g1.cz[1]), "s"(g1.k[0]), "s"(g1.k[1]));
+}
+// Two pairs = four spheres (list positions k0 .. k0 + 3): two packed chains, four compares, one branch for the four of them.
+DEV void filter_pairs(const SphereScanPair &g0, const SphereScanPair &g1, uint32_t k0, const ScanRay32 &f, uint16_t *queue, uint32_t lane,
+                      uint32_t &count)
+{
+    const v2f ux = {f.ux, f.ux}, uy = {f.uy, f.uy}, uz = {f.uz, f.uz}, px = {f.px, f.px}, py = {f.py, f.py}, pz = {f.pz, f.pz}, nt = {f.nthr, f.nthr};
+    const SphereScanPair *g[2] = {&g0, &g1};
+    v2f s[2], q[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const v2f cx = {g[h]->cx[0], g[h]->cx[1]}, cy = {g[h]->cy[0], g[h]->cy[1]}, cz = {g[h]->cz[0], g[h]->cz[1]};
+        s[h] = __builtin_elementwise_fma(cz, uz, __builtin_elementwise_fma(cy, uy, cx * ux));
+        q[h] = __builtin_elementwise_fma(s[h], s[h], __builtin_elementwise_fma(pz, cz, __builtin_elementwise_fma(py, cy, __builtin_elementwise_fma(px, cx, nt))));
+    }
+    const bool p0 = q[0].x > g0.k[0], p1 = q[0].y > g0.k[1], p2 = q[1].x > g1.k[0], p3 = q[1].y > g1.k[1];
+    if (p0 | p1 | p2 | p3) {
+        const bool p[4] = {p0, p1, p2, p3};
+        const float sv[4] = {s[0].x, s[0].y, s[1].x, s[1].y}, qv[4] = {q[0].x, q[0].y, q[1].x, q[1].y};
+        const float kv[4] = {g0.k[0], g0.k[1], g1.k[0], g1.k[1]};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float bu = f.od - sv[u];
+            const bool behind = bu > f.root_m && __builtin_fmaf(bu, bu, kv[u] - qv[u]) > 0.0f;  // k = -inf (always passes): never behind
+            if (p[u] && !behind) {
+                queue[count * 64u + lane] = (uint16_t)(k0 + u);
+                count++;
+            }
+        }
+    }
+}
+
+// Pixel-parallel scan through the packed fp32 filter: pairs of sphere rows are wave-uniform (scalar path), four pairs (eight
+// spheres) per trip in two register sets like scan_filtered; the survivors go through drain_filtered, i.e. the reference's test.
+template <bool ROWS_IN_LDS>
+DEV bool scan_filtered32(const DeviceScene &sc, uint32_t planes_off, uint32_t n_padded, uint16_t *queue, uint32_t lane, const Ray &r, double tmin,
+                         double tmax, HitInfo &best)
+{
+    const SphereScanPair *__restrict__ rows = sc.sphere_scan32;
+    const SphereGeom *__restrict__ spheres = sc.spheres;
+    const uint32_t n = sc.n_spheres;
+    const uint32_t n_pairs = (n + 1u) >> 1, n4 = n_pairs & ~3u;  // the last pair of an odd list is padded with a row that never passes
+    const double a = dot(r.d, r.d);
+    const ScanRay32 f = scan_ray32(r, a, sc.scan_reach32);
+    double closest = tmax;
+    uint32_t best_k = kNone, count = 0;
+    SphereScanPair a0{}, a1{};
+    if (n4) {
+        a0 = load_scan_pair(rows, 0);
+        a1 = load_scan_pair(rows, 1);
+    }
+    for (uint32_t k0 = 0; k0 < n4; k0 += 4) {
+        scan_pairs_arrived(a0, a1);
+        const SphereScanPair b0 = load_scan_pair(rows, k0 + 2), b1 = load_scan_pair(rows, k0 + 3);
+        filter_pairs(a0, a1, 2u * k0, f, queue, lane, count);
+        const uint32_t kn = (k0 + 4 < n4) ? k0 + 4 : k0;  // last trip re-reads its own rows (stays in bounds)
+        scan_pairs_arrived(b0, b1);
+        a0 = load_scan_pair(rows, kn);
+        a1 = load_scan_pair(rows, kn + 1);
+        filter_pairs(b0, b1, 2u * k0 + 4u, f, queue, lane, count);
+        if (__any(count > (uint32_t)(kQueueCap - 8))) drain_filtered<ROWS_IN_LDS>(spheres, planes_off, n_padded, queue, lane, count, r, a, tmin, closest, best_k);
+    }
+    for (uint32_t k = n4; k < n_pairs; k++) {  // up to three pairs left: one at a time, the second half of the call idle
+        const SphereScanPair g = load_scan_pair(rows, k);
+        const float inf = __builtin_inff();
+        const SphereScanPair none{{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {inf, inf}};
+        filter_pairs(g, none, 2u * k, f, queue, lane, count);
+        if (__any(count > (uint32_t)(kQueueCap - 4))) drain_filtered<ROWS_IN_LDS>(spheres, planes_off, n_padded, queue, lane, count, r, a, tmin, closest, best_k);
+    }
+    drain_filtered<ROWS_IN_LDS>(spheres, planes_off, n_padded, queue, lane, count, r, a, tmin, closest, best_k);
+    if (best_k == kNone) return false;
+    best.t = closest;
+    best.ref = make_ref(REF_SPHERE, best_k);
+    best.obj = kNone;
+    return true;
+}
+
 // Pixel-parallel scan through the filter: sphere rows are wave-uniform (scalar path), eight per trip in two register sets
 // as in scan_uniform below.
 template <bool ROWS_IN_LDS>
@@ -2906,9 +3033,11 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             if (boost) todo = overdue;
             if (!boost && a.pixels_per_wave >= 64 && __popcll(live) >= a.coop_threshold) {
                 PH_BEGIN();
-                if (active) hit = a.exact_scan ? scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h)
-                                 : sv.in_lds ? scan_filtered<true>(sc, sv.planes_off, sv.n_padded, queue, lane, ray, 0.001, DBL_MAX, h)
-                                             : scan_filtered<false>(sc, 0u, 0u, queue, lane, ray, 0.001, DBL_MAX, h);
+                if (active) hit = a.exact_scan    ? scan_uniform(sc, queue, lane, ray, 0.001, DBL_MAX, h)
+                                 : a.filter_fp64 ? (sv.in_lds ? scan_filtered<true>(sc, sv.planes_off, sv.n_padded, queue, lane, ray, 0.001, DBL_MAX, h)
+                                                              : scan_filtered<false>(sc, 0u, 0u, queue, lane, ray, 0.001, DBL_MAX, h))
+                                 : sv.in_lds     ? scan_filtered32<true>(sc, sv.planes_off, sv.n_padded, queue, lane, ray, 0.001, DBL_MAX, h)
+                                                 : scan_filtered32<false>(sc, 0u, 0u, queue, lane, ray, 0.001, DBL_MAX, h);
                 PH_END(0, active);
             } else {
                 PH_BEGIN();
@@ -3306,7 +3435,7 @@ hipError_t RT_CAT(launch_seed_, RT_SUFFIX)(const SeedArgs &a, hipStream_t stream
 
 namespace {
 #ifndef RT_WAVES_SPHERES
-#define RT_WAVES_SPHERES 2
+#define RT_WAVES_SPHERES 3  // three workgroups per CU serve the heavy and the light pixels (rt_render_launch): 168 VGPRs at most
 #endif
 #ifndef RT_WAVES_BVH
 #define RT_WAVES_BVH 3

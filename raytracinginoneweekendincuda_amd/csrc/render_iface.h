@@ -59,6 +59,7 @@ struct RenderArgs {
     int32_t heavy_scan;     // sphere BVH worlds: the waves that serve the heavy pixels scan all leaves instead of walking
     int32_t accelerate_lists;  // list worlds of primitives: walk the library's tree instead of scanning the list
     int32_t exact_scan;     // sphere-list worlds: no conservative filter in front of the reference's sphere test
+    int32_t filter_fp64;    // sphere-list worlds: the fp64 form of that filter, one sphere at a time (default: packed fp32, two at a time)
     int32_t reference_tree; // primitive BVH worlds: walk the reference's own tree in its own order (default: the library's SAH tree)
     int32_t always_walk;    // BVH worlds: walk the tree even where a scan of all leaves would be used (small scenes)
     int32_t force_general;  // tests: use the general kernel even where a specialised one applies

@@ -1130,6 +1130,40 @@ int flatten_scene(SceneImpl &s)
             f.scan_reach = std::max(f.scan_reach, reach);
         }
         f.scan_reach *= 1.0 + 0x1p-40;  // the two square roots above were rounded
+        // The packed fp32 form (flat_scene.h SphereScanPair).  Its margin grows with the square of the reach it has to cover, so
+        // the few spheres that lie far outside the bulk -- the Book-1 ground sphere: |c| + r = 2000 in a scene of 15 -- are not
+        // decided by it at all (k = -inf: always on to the exact test); the bulk is what stays within four times the median reach.
+        {
+            std::vector<double> reach(f.sphere_scan.size(), 0.0);
+            for (size_t k = 0; k < f.sphere_scan.size(); k++) {
+                const SphereScanRow &r = f.sphere_scan[k];
+                const SphereGeom &g = f.spheres[k];
+                reach[k] = std::isfinite(r.k) ? std::sqrt(r.cx * r.cx + r.cy * r.cy + r.cz * r.cz) + std::sqrt(std::fabs(g.r2)) : 0.0;
+            }
+            std::vector<double> sorted = reach;
+            std::sort(sorted.begin(), sorted.end());
+            const double bulk = sorted.empty() ? 0.0 : 4.0 * sorted[sorted.size() / 2];
+            f.scan_reach32 = 0.0;
+            f.sphere_scan32.assign((f.sphere_scan.size() + 1) / 2, SphereScanPair{});
+            const float inf = std::numeric_limits<float>::infinity();
+            for (size_t k = 0; k < 2 * f.sphere_scan32.size(); k++) {
+                SphereScanPair &pr = f.sphere_scan32[k / 2];
+                const int h = (int)(k & 1);
+                if (k >= f.sphere_scan.size()) {  // padding: never passes
+                    pr.cx[h] = pr.cy[h] = pr.cz[h] = 0.0f;
+                    pr.k[h] = inf;
+                    continue;
+                }
+                const SphereScanRow &r = f.sphere_scan[k];
+                const bool decided = std::isfinite(r.k) && reach[k] <= bulk && reach[k] < 1e15;
+                pr.cx[h] = decided ? (float)r.cx : 0.0f;
+                pr.cy[h] = decided ? (float)r.cy : 0.0f;
+                pr.cz[h] = decided ? (float)r.cz : 0.0f;
+                pr.k[h] = decided ? (float)r.k : -inf;
+                if (decided) f.scan_reach32 = std::max(f.scan_reach32, reach[k]);
+            }
+            f.scan_reach32 *= 1.0 + 0x1p-20;
+        }
     }
     {
         bool unit_time = !f.mspheres.empty();

@@ -60,6 +60,8 @@ struct FlatScene {
     std::vector<SphereGeom> spheres;
     std::vector<SphereScanRow> sphere_scan;  // parallel to spheres
     double scan_reach = 0.0;
+    std::vector<SphereScanPair> sphere_scan32;  // pairs of sphere_scan rows in fp32
+    double scan_reach32 = 0.0;
     std::vector<SphereAux> sphere_aux;
     std::vector<MSphereGeom> mspheres;
     std::vector<double> ms_planes;       // SCENE_WORLD_MSPHERES: seven planes of ms_padded doubles (see DeviceScene)

@@ -654,6 +654,10 @@ def test_filtered_list_scan_gives_the_exact_scans_frame(oracle, scene_id, shape,
     assert st_a.rays == st_b.rays
     a, b = film_a.download(), film_b.download()
     assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    # the default filter is the packed fp32 form (two spheres per instruction); the fp64 form is the same frame again
+    film_c = rt.Film(w, h)
+    st_c = film_c.render(s, spp, variant=variant, flags=rt.FLAG_FILTER_FP64)
+    assert st_c.rays == st_a.rays and np.array_equal(film_c.download().view(np.uint64), a.view(np.uint64))
     if variant == 0:
         rows = (h // 2, h // 2 + 2)
         want = oracle.render(scene_id, 1, w, h, spp, rows=rows)

@@ -230,6 +230,20 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.quads, d.quads);
     up(f.quad_aa, d.quad_aa);
     up(f.boxes, d.boxes);
+    {
+        // render.hip box_closest: m = 2^-30 (|mn| + |mx|) per axis; in = [mn + m, mx - m], out = [mn - m, mx + m]
+        std::vector<BoxBounds> bounds(f.boxes.size());
+        for (size_t k = 0; k < bounds.size(); k++)
+            for (int a = 0; a < 3; a++) {
+                const double mn = f.boxes[k].mn[a], mx = f.boxes[k].mx[a];
+                const double m = 9.313225746154785e-10 * (std::fabs(mn) + std::fabs(mx));
+                bounds[k].in_lo[a] = mn + m;
+                bounds[k].in_hi[a] = mx - m;
+                bounds[k].out_lo[a] = mn - m;
+                bounds[k].out_hi[a] = mx + m;
+            }
+        up(bounds, d.box_bounds);
+    }
     up(f.quad_mat, d.quad_mat);
     up(f.objects, d.objects);
     up(f.items, d.items);
@@ -490,6 +504,7 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
     ra.accelerate_lists = (p->flags & RT_FLAG_ACCELERATE_LISTS) ? 1 : 0;
     ra.filter_fp64 = tune("RTOW_FILTER_FP64", (p->flags & RT_FLAG_FILTER_FP64) ? 1 : 0, 0, 1);
     ra.heavy_scan = tune("RTOW_HEAVY_SCAN", 0, 0, 1);
+    ra.list_waves = tune("RTOW_LIST_WAVES", 0, 0, 5);
     ra.small_world = tune("RTOW_SMALL_WORLD", 64, 0, 1 << 20);  // scan budget in half sphere tests, see FlatScene::scan_cost
     const DeviceScene &ds = s.device[f.device]->scene;
     HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
@@ -713,8 +728,8 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
         }
         if (tune_set("RTOW_PRINT_STAMPS")) {  // diagnostic builds (-DRT_STAMP=1): 100 MHz wall-clock ticks
             const unsigned long long *st = f.host_counters;
-            std::fprintf(stderr, "stamps: start %llu  queue exhausted +%.3f ms  first wave out +%.3f ms  last wave out +%.3f ms\n",
-                         st[5], (st[2] - st[5]) * 1e-5, (st[4] - st[5]) * 1e-5, (st[3] - st[5]) * 1e-5);
+            std::fprintf(stderr, "stamps: start %llu  queue exhausted +%.3f ms  first wave out +%.3f ms  last wave out +%.3f ms  heavy pixels done +%.3f ms\n",
+                         st[5], (st[2] - st[5]) * 1e-5, (st[4] - st[5]) * 1e-5, (st[3] - st[5]) * 1e-5, st[8] ? (st[8] - st[5]) * 1e-5 : 0.0);
         }
         if (tune_set("RTOW_PRINT_PHASES")) {  // diagnostic builds (-DRT_PHASES=1)
             const unsigned long long *c = f.host_counters;

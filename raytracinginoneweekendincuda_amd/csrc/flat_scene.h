@@ -56,6 +56,9 @@ struct AAQuad { double na, d, wa, qp, qq, ku, kv; uint32_t code, pad; };  // cod
 // than 2^-30 of the coordinates' magnitude is accepted, one that is outside by as much is rejected, and only the
 // sliver in between evaluates the face's own alpha / beta (render.hip box_closest has the bound).
 struct BoxRec { double na[6], d[6], mn[3], mx[3]; uint32_t quad_first, pad; };
+// The four bounds of that sliver, worked out once per box instead of once per ray (device_scene.cpp): list-world kernels read them
+// through scalar loads -- every lane is on the same box -- and compare against them straight from scalar registers.
+struct BoxBounds { double in_lo[3], in_hi[3], out_lo[3], out_hi[3]; };
 
 // Instance transform step (R/Instance.h:31-37 Translate, :74-112 RotateY).
 enum : uint32_t { XF_TRANSLATE = 0u, XF_ROTATE_Y = 1u };
@@ -190,6 +193,7 @@ struct DeviceScene {
     const QuadGeom *quads;
     const AAQuad *quad_aa;        // parallel to quads
     const BoxRec *boxes;
+    const BoxBounds *box_bounds;  // one per box
     const uint32_t *quad_mat;
     const ObjectRec *objects;
     const uint32_t *items;        // GEOM_MIXED entries (prim refs)
@@ -233,6 +237,7 @@ struct DeviceScene {
     uint32_t lds_quad_aa, lds_boxes, lds_objects, lds_xforms, lds_media, lds_materials, lds_perlin, lds_spheres_tab, lds_group_boxes,
         lds_mspheres, lds_msphere_aux, lds_sphere_aux;  // the primitive tables of a sphere world (library-tree kernel, one workgroup per CU)
     uint32_t lds_fast_order, lds_seg_media, lds_seg_cand;  // segmented walk: always staged (render.hip launch_one)
+    uint32_t lds_park;  // parked path state of the instanced-list kernel (render.hip Traits::PARK)
     uint32_t flags;
 };
 

@@ -54,13 +54,23 @@ namespace {
 //   FAST       primitive-only BVH world walked through the library's own SAH tree, near child first (flat_scene.h FastNodeRec)
 //              (with COMPOSITE and BATCH: the segmented walk of a composite world, Traits::SEG)
 //   GROUPED    list scan with the leaves of every ray dealt to several lanes (scan_leaves_grouped): launches with pixels_per_wave < 64
+#ifndef RT_PARK_STATE
+#define RT_PARK_STATE 1
+#endif
+#ifndef RT_BIG_BLOCK
+#define RT_BIG_BLOCK 768  // workgroups this large run one per CU with the scene tables in (nearly) all of its LDS
+#endif
 template <int WORLD_, bool COMPOSITE_, bool RICH_, int MIN_WAVES_ = 1, bool MEDIA_ = COMPOSITE_, bool BATCH_ = false, bool NESTED_ = false,
           int BLOCK_ = 256, bool FAST_ = false, bool GROUPED_ = false>
 struct Traits {
     static constexpr bool GROUPED = GROUPED_ && WORLD_ == 1 && !MEDIA_ && !NESTED_;
+    // list scan over instances / boxes compiled for five waves per SIMD (C4, TListInstances5): the path state the scan does not touch
+    // -- pixel sum, throughput, emitted light, RNG, pixel counters -- waits in LDS while the leaves are tested (park_* in
+    // render_kernel), so that 96 registers are nearly enough (at four waves the same parking costs 2.5 %: measured, not used)
+    static constexpr bool PARK = RT_PARK_STATE && WORLD_ == 1 && COMPOSITE_ && !RICH_ && !MEDIA_ && !NESTED_ && !GROUPED_ && MIN_WAVES_ >= 5;
     // segmented walk (flat_scene.h FastOrder / SegMedium): the library's tree over the surface leaves of a composite BVH world,
     // walked once per run of leaves between two media; kind-batched leaf phases, one 768-thread workgroup per CU
-    static constexpr bool SEG = FAST_ && COMPOSITE_ && BATCH_ && WORLD_ == 0 && BLOCK_ >= 768;
+    static constexpr bool SEG = FAST_ && COMPOSITE_ && BATCH_ && WORLD_ == 0 && BLOCK_ >= RT_BIG_BLOCK;
     static constexpr bool FAST = FAST_ && !COMPOSITE_ && WORLD_ == 0;
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool NESTED = NESTED_ && COMPOSITE_;
@@ -324,8 +334,11 @@ DEV bool quad_test_at(const DeviceScene &sc, uint32_t idx, const Ray &r, double 
 //   mn[p] + m <= P[p] <= mx[p] - m  =>  2^-30 <= (P[p] - Q[p]) / u[p] <= 1 - 2^-31  =>  alpha in [0, 1] for certain;
 //   P[p] < mn[p] - m or P[p] > mx[p] + m  =>  alpha < 0 or alpha > 1 for certain;
 // the same for beta along q.  Only a hit point inside the 2m sliver around an edge needs alpha / beta themselves.
+// PRE: the sliver's bounds come from the host's table (BoxBounds) through scalar loads -- list-world kernels, where `box` is
+// the same for every lane; otherwise they are computed here from the box's corners.
+template <bool PRE = false>
 DEV bool box_closest(const DeviceScene &sc, const BoxRec &bx, const Ray &r, double tmin, double tmax, double &t_best,
-                     uint32_t &ref_best)
+                     uint32_t &ref_best, [[maybe_unused]] uint32_t box = 0u)
 {
     double t[6];
     bool ok[6];
@@ -335,10 +348,19 @@ DEV bool box_closest(const DeviceScene &sc, const BoxRec &bx, const Ray &r, doub
     ok[3] = aa_plane<0>(bx.na[3], bx.d[3], r, tmin, tmax, t[3]);  // left
     ok[4] = aa_plane<1>(bx.na[4], bx.d[4], r, tmin, tmax, t[4]);  // top
     ok[5] = aa_plane<1>(bx.na[5], bx.d[5], r, tmin, tmax, t[5]);  // bottom
-    const Vec mn = mk(bx.mn[0], bx.mn[1], bx.mn[2]), mx = mk(bx.mx[0], bx.mx[1], bx.mx[2]);
-    const double k30 = 9.313225746154785e-10;  // 2^-30
-    const Vec m = mk(k30 * (fabs(mn.x) + fabs(mx.x)), k30 * (fabs(mn.y) + fabs(mx.y)), k30 * (fabs(mn.z) + fabs(mx.z)));
-    const Vec in_lo = mn + m, in_hi = mx - m, out_lo = mn - m, out_hi = mx + m;
+    Vec in_lo, in_hi, out_lo, out_hi;
+    if constexpr (PRE) {
+        const RT_CONST double *bb = const_doubles(sc.box_bounds + box);
+        in_lo = mk(bb[0], bb[1], bb[2]);
+        in_hi = mk(bb[3], bb[4], bb[5]);
+        out_lo = mk(bb[6], bb[7], bb[8]);
+        out_hi = mk(bb[9], bb[10], bb[11]);
+    } else {
+        const Vec mn = mk(bx.mn[0], bx.mn[1], bx.mn[2]), mx = mk(bx.mx[0], bx.mx[1], bx.mx[2]);
+        const double k30 = 9.313225746154785e-10;  // 2^-30
+        const Vec m = mk(k30 * (fabs(mn.x) + fabs(mx.x)), k30 * (fabs(mn.y) + fabs(mx.y)), k30 * (fabs(mn.z) + fabs(mx.z)));
+        in_lo = mn + m; in_hi = mx - m; out_lo = mn - m; out_hi = mx + m;
+    }
     const uint32_t quad_first = bx.quad_first;
     double closest = tmax;
     bool any = false;
@@ -489,6 +511,7 @@ DEV bool subbvh_closest(const DeviceScene &sc, uint32_t root, const Ray &lr, dou
 }
 
 // Closest hit over a composite leaf's geometry (R/HittableList.h:39-57 for groups).
+template <bool UNIFORM = false>  // every lane is on the same object (list-world kernels)
 DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, double tmin, double tmax,
                       double &t_best, uint32_t &ref_best)
 {
@@ -529,7 +552,7 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
         }
         break;
     case GEOM_BOX:
-        any = box_closest(sc, get_box(sc, o.first), lr, tmin, tmax, closest, ref_best);
+        any = box_closest<UNIFORM>(sc, get_box(sc, o.first), lr, tmin, tmax, closest, ref_best, o.first);
         break;
     case GEOM_QUADS:
         for (uint32_t k = 0; k < o.count; k++) {
@@ -606,7 +629,7 @@ DEV bool object_span(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
             const double hi = medium ? DBL_MAX : tmax;
             double t;
             PH_SUB_BEGIN();
-            const bool got = geom_closest(sc, o, lr, lo, hi, t, pref);
+            const bool got = geom_closest<T::WORLD == 1 && !T::GROUPED>(sc, o, lr, lo, hi, t, pref);
 #if RT_PHASES
             asm volatile("" ::"v"(t));
 #endif
@@ -860,7 +883,7 @@ DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
             PH_SUB_BEGIN();
             double t;
             uint32_t face = kNone;
-            const bool found = box_closest(sc, get_box(sc, ref & kRefIndexMask), r, tmin, tmax, t, face);
+            const bool found = box_closest<T::WORLD == 1 && !T::GROUPED>(sc, get_box(sc, ref & kRefIndexMask), r, tmin, tmax, t, face, ref & kRefIndexMask);
             if (found) {
                 best.t = t;
                 best.ref = face;
@@ -2744,6 +2767,59 @@ __global__ __launch_bounds__(256) void seed_kernel(SeedArgs a)
 }
 
 
+#if RT_PHASES
+DEV void ph_flush(const RenderArgs &a, PhaseSums &ph, unsigned long long ph_start, uint32_t lane)
+{
+    for (int k = 4; k < 15; k++) {
+        if (k == 12 || k == 13) continue;  // wave-level slots
+        for (int off = 32; off > 0; off >>= 1) {
+            ph.t[k] += __shfl_down(ph.t[k], off, 64);
+            ph.l[k] += __shfl_down(ph.l[k], off, 64);
+            ph.n[k] += __shfl_down(ph.n[k], off, 64);
+        }
+        ph.t[k] >>= 10;
+        ph.l[k] >>= 10;
+        ph.n[k] >>= 10;
+    }
+    if (lane == 0) {
+        for (int k = 0; k < 24; k++) {
+            atomicAdd(a.ray_counter + 32 + k, ph.t[k]);
+            atomicAdd(a.ray_counter + 64 + k, ph.l[k]);
+            atomicAdd(a.ray_counter + 96 + k, ph.n[k]);
+        }
+        atomicAdd(a.ray_counter + 7, __builtin_readcyclecounter() - ph_start);
+    }
+}
+#endif
+// Parked path state (Traits::PARK): twelve 8-byte planes of BLOCK entries behind the staged tables, one entry per thread.
+template <int BLOCK>
+DEV void park_put(uint32_t off, int k, double v) { *(RT_LDS double *)(lds_raw + off + ((uint32_t)k * (uint32_t)BLOCK + threadIdx.x) * 8u) = v; }
+template <int BLOCK>
+DEV double park_get(uint32_t off, int k) { return *(const RT_LDS double *)(lds_raw + off + ((uint32_t)k * (uint32_t)BLOCK + threadIdx.x) * 8u); }
+template <int BLOCK>
+DEV void park_put_vec(uint32_t off, int k, Vec v) { park_put<BLOCK>(off, k, v.x); park_put<BLOCK>(off, k + 1, v.y); park_put<BLOCK>(off, k + 2, v.z); }
+template <int BLOCK>
+DEV Vec park_get_vec(uint32_t off, int k) { return mk(park_get<BLOCK>(off, k), park_get<BLOCK>(off, k + 1), park_get<BLOCK>(off, k + 2)); }
+template <int BLOCK>
+DEV void park_put_rng(uint32_t off, const Xorwow &g)
+{
+    RT_LDS uint32_t *p = (RT_LDS uint32_t *)(lds_raw + off + (9u * (uint32_t)BLOCK) * 8u);
+    p[0 * BLOCK + threadIdx.x] = g.d;  p[1 * BLOCK + threadIdx.x] = g.v0; p[2 * BLOCK + threadIdx.x] = g.v1;
+    p[3 * BLOCK + threadIdx.x] = g.v2; p[4 * BLOCK + threadIdx.x] = g.v3; p[5 * BLOCK + threadIdx.x] = g.v4;
+}
+template <int BLOCK>
+DEV void park_get_rng(uint32_t off, Xorwow &g)
+{
+    const RT_LDS uint32_t *p = (const RT_LDS uint32_t *)(lds_raw + off + (9u * (uint32_t)BLOCK) * 8u);
+    g.d = p[0 * BLOCK + threadIdx.x];  g.v0 = p[1 * BLOCK + threadIdx.x]; g.v1 = p[2 * BLOCK + threadIdx.x];
+    g.v2 = p[3 * BLOCK + threadIdx.x]; g.v3 = p[4 * BLOCK + threadIdx.x]; g.v4 = p[5 * BLOCK + threadIdx.x];
+}
+// ... and five 4-byte planes behind them: pixel column, row, index in the rank's buffer, sample number, rays of the pixel so far
+template <int BLOCK>
+DEV void park_put_int(uint32_t off, int k, uint32_t v) { *(RT_LDS uint32_t *)(lds_raw + off + (24u + (uint32_t)k) * (uint32_t)BLOCK * 4u + threadIdx.x * 4u) = v; }
+template <int BLOCK>
+DEV uint32_t park_get_int(uint32_t off, int k) { return *(const RT_LDS uint32_t *)(lds_raw + off + (24u + (uint32_t)k) * (uint32_t)BLOCK * 4u + threadIdx.x * 4u); }
+constexpr size_t kParkBytesPerThread = 12 * 8 + 5 * 4;  // col, throughput, accumulated: 9 doubles; RNG: 6 words; 5 counters
 template <int STRICT, class T>
 __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceScene sc, RenderArgs a)
 {
@@ -2758,17 +2834,17 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     } else if constexpr (T::FAST) {
         sc.lds_quad_aa = sc.lds_boxes = sc.lds_objects = sc.lds_xforms = sc.lds_media = sc.lds_perlin = sc.lds_group_boxes = kNone;
 #ifndef RT_NO_ASSUME
-        if constexpr (T::BLOCK >= 768) {  // launched only with all of its rows staged (launch_one)
+        if constexpr (T::BLOCK >= RT_BIG_BLOCK) {  // launched only with all of its rows staged (launch_one)
             __builtin_assume(sc.lds_mspheres != kNone && sc.lds_msphere_aux != kNone && sc.lds_spheres_tab != kNone);
             __builtin_assume(sc.lds_sphere_aux != kNone && sc.lds_materials != kNone);
         }
 #endif
     } else {
         sc.lds_mspheres = sc.lds_msphere_aux = sc.lds_sphere_aux = kNone;
-        if constexpr (T::BLOCK < 768) sc.lds_spheres_tab = kNone;
+        if constexpr (T::BLOCK < RT_BIG_BLOCK) sc.lds_spheres_tab = kNone;
         if constexpr (!T::RICH) sc.lds_perlin = kNone;
 #ifndef RT_NO_ASSUME
-        if constexpr (T::BATCH && T::BLOCK >= 768) {  // the deep kernel is launched only with all of these staged (launch_one)
+        if constexpr (T::BATCH && T::BLOCK >= RT_BIG_BLOCK) {  // the deep kernel is launched only with all of these staged (launch_one)
             __builtin_assume(sc.lds_boxes != kNone && sc.lds_objects != kNone && sc.lds_xforms != kNone);
             __builtin_assume(sc.lds_media != kNone && sc.lds_materials != kNone && sc.lds_perlin != kNone);
             __builtin_assume(sc.lds_spheres_tab != kNone && sc.lds_group_boxes != kNone);
@@ -2782,7 +2858,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     if constexpr (T::WORLD == 0) {
         // BVH nodes in LDS, one 72-byte row each (see lds_node_f64 for the layout and why 72)
         nv.global = sc.nodes;
-        nv.in_lds = (T::BATCH && T::BLOCK >= 768) ? true : a.lds_nodes != 0;  // the deep kernel: always (launch_one)
+        nv.in_lds = (T::BATCH && T::BLOCK >= RT_BIG_BLOCK) ? true : a.lds_nodes != 0;  // the deep kernel: always (launch_one)
         if constexpr (T::FAST) {
             {  // the library's own tree: rows copied as they are (always staged: see walk_node_fast)
                 const uint32_t words = sc.n_fast_nodes * (kFastNodeBytes / 4u);
@@ -2899,7 +2975,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     Vec throughput = mk(1.0, 1.0, 1.0), accumulated = mk(0.0, 0.0, 0.0);
     Ray ray{};
     int sample = 0, depth = 0;
-    uint32_t nrays = 0;
+    uint32_t wave_rays = 0;  // rays of the whole wave (uniform)
 
     uint32_t pix_rays = 0;  // rays this lane's current pixel has traced so far
     uint32_t my_tile = 0;   // tile of the current pixel (cost probe)
@@ -2919,6 +2995,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #if RT_PHASES
     PhaseSums ph{};
     const unsigned long long ph_start = __builtin_readcyclecounter();
+    bool ph_serving = heavy_mode;  // RT_PHASES == 2: only the waves serving heavy pixels report, and only that part of their life
 #endif
     for (;;) {
         // A pixel that has used up its ray budget is "overdue": its samples cannot be spread over lanes (one
@@ -2999,6 +3076,17 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                         if (RT_PROBE_ON) my_tile = tile;
                         ray = camera_ray(cam, i, j, a.width, a.height, rng);
                         active = true;
+                        if constexpr (T::PARK) {
+                            park_put_int<T::BLOCK>(sc.lds_park, 0, (uint32_t)i);
+                            park_put_int<T::BLOCK>(sc.lds_park, 1, (uint32_t)j);
+                            park_put_int<T::BLOCK>(sc.lds_park, 2, (uint32_t)local);
+                            park_put_int<T::BLOCK>(sc.lds_park, 3, 0u);
+                            park_put_int<T::BLOCK>(sc.lds_park, 4, 0u);
+                            park_put_vec<T::BLOCK>(sc.lds_park, 0, col);
+                            park_put_vec<T::BLOCK>(sc.lds_park, 3, throughput);
+                            park_put_vec<T::BLOCK>(sc.lds_park, 6, accumulated);
+                            park_put_rng<T::BLOCK>(sc.lds_park, rng);
+                        }
                         if constexpr (T::WORLD == 0) {
                             walk_begin<T::FAST || T::SEG>(walk, ray, DBL_MAX);
                             if constexpr (T::SEG) {  // "between walks", before the first one: seg_advance at the head of the next round
@@ -3016,6 +3104,13 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             if (heavy_mode && heavy_dry) {  // the list is done and so are this wave's heavy pixels: join the tile queue
                 heavy_mode = false;
                 __builtin_amdgcn_s_setprio(0);
+#if RT_PHASES == 2
+                ph_flush(a, ph, ph_start, lane);
+                ph_serving = false;
+#endif
+#if RT_STAMP
+                if (lane == 0 && !a.probe) atomicMax(a.ray_counter + 8, (unsigned long long)wall_clock64());  // last serving wave done with the heavy list
+#endif
                 continue;
             }
             if (exhausted) break;
@@ -3109,9 +3204,6 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                                     walk_node_fast(ray, 0.001, walk);
                                     PH_COUNT(14);
                                 }
-#if RT_FAST_VISITS >= 3
-                                if (walk_moving(walk.state)) walk_node_fast(ray, 0.001, walk);
-#endif
                             } else if constexpr (T::SEG) {
                                 if (limited_walks) {  // some lane of the wave is on its way to a medium (wave-uniform, rare)
                                     walk_node_seg(sc, ray, 0.001, walk, seg.hi);
@@ -3211,13 +3303,22 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             scan_leaves_grouped<T>(sc, lane, 6 - (__ffs(a.pixels_per_wave) - 1), todo, ray, 0.001, DBL_MAX, h, hit, rng PH_PASS);
             PH_END(1, (todo >> lane) & 1ull);
         }
+        if (a.max_depth > 0) wave_rays += (uint32_t)__popcll(todo);
         if ((todo >> lane) & 1ull) {
             const bool no_bounces = a.max_depth <= 0;  // R/kernel.cu:71: the bounce loop never runs, RayColor returns black
             if (!no_bounces) {
-                nrays++;
-                pix_rays++;
+                if constexpr (T::PARK) {
+                    if (RT_PROBE_ON && a.probe) park_put_int<T::BLOCK>(sc.lds_park, 4, park_get_int<T::BLOCK>(sc.lds_park, 4) + 1u);  // only the rehearsal asks
+                } else {
+                    pix_rays++;
+                }
             }
             if constexpr (T::WORLD == 1 && !T::GROUPED) hit = world_hit_list<T>(sc, ray, 0.001, DBL_MAX, h, rng PH_PASS);
+            if constexpr (T::PARK) {  // back from LDS: what the shading works on (no leaf of these worlds draws random numbers)
+                throughput = park_get_vec<T::BLOCK>(sc.lds_park, 3);
+                accumulated = park_get_vec<T::BLOCK>(sc.lds_park, 6);
+                park_get_rng<T::BLOCK>(sc.lds_park, rng);
+            }
             bool path_ends;
             if (no_bounces) {
                 path_ends = true;
@@ -3253,19 +3354,36 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             }
 #endif
             if (path_ends) {  // R/kernel.cu:143: col += RayColor(...)
+                if constexpr (T::PARK) {
+                    col = park_get_vec<T::BLOCK>(sc.lds_park, 0);
+                    sample = (int)park_get_int<T::BLOCK>(sc.lds_park, 3);
+                }
                 col = col + accumulated;
                 if (++sample < a.spp) {
+                    if constexpr (T::PARK) {
+                        park_put_vec<T::BLOCK>(sc.lds_park, 0, col);
+                        park_put_int<T::BLOCK>(sc.lds_park, 3, (uint32_t)sample);
+                        i = (int)park_get_int<T::BLOCK>(sc.lds_park, 0);
+                        j = (int)park_get_int<T::BLOCK>(sc.lds_park, 1);
+                    }
                     ray = camera_ray(cam, i, j, a.width, a.height, rng);
                     throughput = mk(1.0, 1.0, 1.0);
                     accumulated = mk(0.0, 0.0, 0.0);
                     depth = 0;
                 } else if (RT_PROBE_ON && a.probe) {
                     // cost probe: the samples were a rehearsal (the saved RNG state is untouched); book the rays
+                    if constexpr (T::PARK) {
+                        local = (size_t)park_get_int<T::BLOCK>(sc.lds_park, 2);
+                        pix_rays = park_get_int<T::BLOCK>(sc.lds_park, 4);
+                        const uint32_t row = (uint32_t)local / (uint32_t)a.width, column = (uint32_t)local % (uint32_t)a.width;
+                        my_tile = (row >> 3) * tiles_x + (column >> 3);
+                    }
                     if (a.tile_cost) atomicAdd(a.tile_cost + my_tile, pix_rays);
                     if (a.pix_cost) a.pix_cost[local] = pix_rays;
                     active = false;
                 } else {
                     // R/kernel.cu:146-153: save the RNG state, average, gamma 2
+                    if constexpr (T::PARK) local = (size_t)park_get_int<T::BLOCK>(sc.lds_park, 2);
                     a.state[0 * (size_t)a.n_pixels + local] = rng.d;
                     a.state[1 * (size_t)a.n_pixels + local] = rng.v0;
                     a.state[2 * (size_t)a.n_pixels + local] = rng.v1;
@@ -3288,6 +3406,13 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             asm volatile("" ::"v"(ray.d.x), "v"(col.x));
             ph.t[22] += __builtin_readcyclecounter() - ph_c;  // next camera ray or pixel done (booked together)
 #endif
+            if constexpr (T::PARK) {
+                if (active) {
+                    park_put_vec<T::BLOCK>(sc.lds_park, 3, throughput);
+                    park_put_vec<T::BLOCK>(sc.lds_park, 6, accumulated);
+                    park_put_rng<T::BLOCK>(sc.lds_park, rng);
+                }
+            }
             if constexpr (T::WORLD == 0) {
                 if (active) {
                     walk_begin<T::FAST || T::SEG>(walk, ray, DBL_MAX);
@@ -3309,25 +3434,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
 #endif
     }
 #if RT_PHASES
-    for (int k = 4; k < 15; k++) {
-        if (k == 12 || k == 13) continue;  // wave-level slots
-        for (int off = 32; off > 0; off >>= 1) {
-            ph.t[k] += __shfl_down(ph.t[k], off, 64);
-            ph.l[k] += __shfl_down(ph.l[k], off, 64);
-            ph.n[k] += __shfl_down(ph.n[k], off, 64);
-        }
-        ph.t[k] >>= 10;
-        ph.l[k] >>= 10;
-        ph.n[k] >>= 10;
-    }
-    if (lane == 0) {
-        for (int k = 0; k < 24; k++) {
-            atomicAdd(a.ray_counter + 32 + k, ph.t[k]);
-            atomicAdd(a.ray_counter + 64 + k, ph.l[k]);
-            atomicAdd(a.ray_counter + 96 + k, ph.n[k]);
-        }
-        atomicAdd(a.ray_counter + 7, __builtin_readcyclecounter() - ph_start);
-    }
+    if (RT_PHASES == 1 || ph_serving) ph_flush(a, ph, ph_start, lane);
 #endif
 
 #if RT_STAMP
@@ -3337,8 +3444,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     }
 #endif
     // one atomic per wave for the ray counter
-    unsigned long long total = nrays;
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, 64);
+    const unsigned long long total = wave_rays;
     if (lane == 0 && total) atomicAdd(a.ray_counter, total);
 }
 
@@ -3488,6 +3594,12 @@ using TListPrims = Traits<1, false, false, 4>;  // 127-129 VGPRs without the bou
 #define RT_WAVES_LIST_INSTANCES 4  // 128 VGPRs and 52 B of scratch for a fourth wave per SIMD: C4 +2.4 % (139 VGPRs, none, three waves before)
 #endif
 using TListInstances = Traits<1, true, false, RT_WAVES_LIST_INSTANCES, false>;
+// The same kernel compiled for FIVE waves per SIMD (96 VGPRs and 64 B of scratch with the path state parked in LDS, Traits::PARK).  Its passes take 1.38 times as long
+// -- the SIMDs' issue slots are nearly full with four waves -- so in the steady state it is the slower of the two; but a pixel's
+// samples are one chain, pixels of these worlds all cost about the same, and a frame is therefore a whole number of pixel
+// "generations" on the resident lanes: 800 x 800 pixels are 2.44 generations on the 262 144 lanes of four waves per SIMD -- three,
+// the last 44 % full -- and 1.95 on the 327 680 of five: two.  dispatch() picks by that count (list_instances_waves).
+using TListInstances5 = Traits<1, true, false, 5, false>;
 // The same two with the leaves of every ray dealt to lanes (pixels_per_wave < 64: fewer pixels than lanes, the frame is bound
 // by the latency of a ray, not by throughput -- registers matter more than a fourth wave)
 #ifndef RT_WAVES_GROUPED
@@ -3524,7 +3636,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             lds = need;
             a.lds_nodes = 1;
         }
-        if (T::FAST && T::BLOCK >= 768 && a.lds_nodes) {
+        if (T::FAST && T::BLOCK >= RT_BIG_BLOCK && a.lds_nodes) {
             // One workgroup per CU: the sphere rows the leaf tests and the hit record read and the material rows follow the
             // node rows into the CU's LDS -- a frame ends with its longest pixel, and that pixel's chain is made of exactly
             // these dependent reads (C3: leaf pass 2100 -> ... cycles, shading pass 11000 -> ... cycles).
@@ -3542,7 +3654,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             place(sc.lds_materials, (size_t)sc.n_materials * sizeof(MaterialRec));
             lds = off;
         }
-        if constexpr (T::FAST && T::BLOCK >= 768) {
+        if constexpr (T::FAST && T::BLOCK >= RT_BIG_BLOCK) {
             // The library-tree kernel reads these rows from LDS only (no global side in its accessors: head of
             // render_kernel); a world whose rows do not fit is walked by the reference-tree kernel.
             const bool fits = a.lds_nodes && (sc.n_mspheres == 0 || (sc.lds_mspheres != kNone && sc.lds_msphere_aux != kNone)) &&
@@ -3567,7 +3679,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             // chases through (object -> transforms -> medium; material rows; Perlin tables: a few KB even in the Book-2
             // final scene) and, where they fit as well, the quad / box rows (Cornell box: 2 KB).
             // three 256-thread workgroups per CU share its 160 KB, or one of 768 threads has (nearly) all of it
-            const size_t budget = T::BLOCK >= 768 ? 158 * 1024 : 52 * 1024;
+            const size_t budget = T::BLOCK >= RT_BIG_BLOCK ? 158 * 1024 : 52 * 1024;
             size_t off = (lds + 15) & ~(size_t)15;
             auto place = [&](uint32_t &slot, size_t bytes, size_t cap) {
                 if (bytes == 0 || bytes > cap || off + bytes + 64 > budget) return;
@@ -3581,7 +3693,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             place(sc.lds_materials, (size_t)sc.n_materials * sizeof(MaterialRec), 4096);
             if (T::RICH) place(sc.lds_perlin, (size_t)sc.n_perlin * sizeof(PerlinRec), 2 * sizeof(PerlinRec));
             const size_t b_quads = (size_t)sc.n_quads * sizeof(AAQuad), b_boxes = (size_t)sc.n_boxes * sizeof(BoxRec);
-            if (T::BLOCK >= 768) {  // the big tables, most useful first
+            if (T::BLOCK >= RT_BIG_BLOCK) {  // the big tables, most useful first
                 place(sc.lds_boxes, b_boxes, 80 * 1024);
                 place(sc.lds_spheres_tab, (size_t)sc.n_spheres * sizeof(SphereGeom), 40 * 1024);
                 place(sc.lds_quad_aa, b_quads, 16 * 1024);
@@ -3590,7 +3702,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
                 place(sc.lds_boxes, b_boxes, 16 * 1024);
             }
             lds = off;
-            if constexpr (T::BATCH && T::BLOCK >= 768) {
+            if constexpr (T::BATCH && T::BLOCK >= RT_BIG_BLOCK) {
                 // The deep kernel reads its node rows and every table from LDS only (its accessors have no global side: see
                 // the head of render_kernel).  A scene that does not fit goes to the general kernel, which reads what is
                 // not staged from L2.
@@ -3618,6 +3730,11 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
             lds += planes;
             a.lds_spheres = 1;
         }
+    }
+    if constexpr (T::PARK) {  // the parked path state, one entry per thread (list worlds stage no tables: their rows come through scalar loads)
+        const size_t off = (lds + 15) & ~(size_t)15;
+        sc.lds_park = (uint32_t)off;
+        lds = off + (size_t)T::BLOCK * kParkBytesPerThread;
     }
     if (info) {
         hipFuncAttributes attr;
@@ -3658,7 +3775,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
 
 // instantiations of group 1, by id (defined in the RT_GROUP == 1 translation unit)
 enum CompositeKernel { CK_LIST_PRIMS, CK_LIST_INSTANCES, CK_LIST_GENERAL, CK_LIST_NESTED, CK_BVH_INSTANCES, CK_BVH_MEDIA,
-                       CK_BVH_GENERAL, CK_BVH_GENERAL_DEEP, CK_BVH_NESTED, CK_LIST_PRIMS_GROUPED, CK_LIST_INSTANCES_GROUPED, CK_BVH_SEGMENTED };
+                       CK_BVH_GENERAL, CK_BVH_GENERAL_DEEP, CK_BVH_NESTED, CK_LIST_PRIMS_GROUPED, CK_LIST_INSTANCES_GROUPED, CK_BVH_SEGMENTED, CK_LIST_INSTANCES_5 };
 hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info);
 
 #if RT_GROUP == 1
@@ -3667,6 +3784,7 @@ hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc
     switch (which) {
     case CK_LIST_PRIMS: return launch_one<TListPrims>(sc, a, stream, info);
     case CK_LIST_INSTANCES: return launch_one<TListInstances>(sc, a, stream, info);
+    case CK_LIST_INSTANCES_5: return launch_one<TListInstances5>(sc, a, stream, info);
     case CK_LIST_PRIMS_GROUPED: return launch_one<TListPrimsGrouped>(sc, a, stream, info);
     case CK_LIST_INSTANCES_GROUPED: return launch_one<TListInstancesGrouped>(sc, a, stream, info);
     case CK_LIST_GENERAL: return launch_one<TListGeneral>(sc, a, stream, info);
@@ -3681,6 +3799,20 @@ hipError_t RT_CAT(launch_composite_, RT_SUFFIX)(int which, const DeviceScene &sc
 }
 #else
 namespace {
+// Four or five waves per SIMD for the instanced-list kernel (TListInstances5): whole generations of pixels on the resident
+// lanes times the duration of a pass at that occupancy (1 : 1.38, measured on C4: three generations of 85.7 ms against two of
+// 118.6).  A frame that does not fill the lanes of four waves stays there: its time is its pixels' chains, and a pass is shortest
+// with the fewest waves.
+int list_instances_waves(const RenderArgs &a)
+{
+    if (a.list_waves == 4 || a.list_waves == 5) return a.list_waves;  // RT_TUNING builds / tests
+    const double pixels = (double)a.width * (double)a.rows_owned;
+    const double cus = a.num_cus > 0 ? (double)a.num_cus : 256.0;
+    const double gen4 = std::ceil(pixels / (cus * 16.0 * 64.0) - 0.02), gen5 = std::ceil(pixels / (cus * 20.0 * 64.0) - 0.02);
+    if (gen4 <= 1.0) return 4;
+    return gen5 * 1.38 < gen4 ? 5 : 4;
+}
+
 hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stream, KernelInfo *info)
 {
     auto composite_kernel = [&](int which) { return RT_CAT(launch_composite_, RT_SUFFIX)(which, sc, a, stream, info); };
@@ -3699,6 +3831,7 @@ hipError_t dispatch(const DeviceScene &sc, const RenderArgs &a, hipStream_t stre
         // pixels_per_wave < 64 (a power of two: rt_render_launch): the instantiation that deals a ray's leaves to lanes
         const bool grouped = a.pixels_per_wave < 64 && (a.pixels_per_wave & (a.pixels_per_wave - 1)) == 0 && a.pixels_per_wave > 0;
         if (grouped) return composite_kernel(composite ? CK_LIST_INSTANCES_GROUPED : CK_LIST_PRIMS_GROUPED);
+        if (composite && list_instances_waves(a) == 5) return composite_kernel(CK_LIST_INSTANCES_5);
         return composite_kernel(composite ? CK_LIST_INSTANCES : CK_LIST_PRIMS);
     }
     if (sc.world_kind == WORLD_BVH) {

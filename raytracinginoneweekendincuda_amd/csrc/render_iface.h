@@ -56,6 +56,7 @@ struct RenderArgs {
     int32_t object_batch;   // the same for instances / groups (their cooperative scan serves one ray at a time: a small batch is fine)
     int32_t lds_nodes;      // set by the launcher: BVH nodes are staged in LDS
     int32_t small_world;    // BVH worlds without media are scanned, not walked, up to this scan cost (and 16 leaves)
+    int32_t list_waves;     // instanced-list kernel: 4 or 5 waves per SIMD, 0 = by the frame's pixel generations (render.hip list_instances_waves)
     int32_t heavy_scan;     // sphere BVH worlds: the waves that serve the heavy pixels scan all leaves instead of walking
     int32_t accelerate_lists;  // list worlds of primitives: walk the library's tree instead of scanning the list
     int32_t exact_scan;     // sphere-list worlds: no conservative filter in front of the reference's sphere test

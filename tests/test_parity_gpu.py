@@ -86,6 +86,33 @@ def test_stripe_partition_is_bit_identical_to_one_gpu(world):
     assert np.array_equal(out.view(np.uint64), full.view(np.uint64))
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_instanced_list_kernel_on_five_waves_per_simd_gives_the_four_wave_frame(variant):
+    """C4's world is scanned by one of two builds of the same kernel: four waves per SIMD, or five with the path state parked in
+    LDS (render.hip Traits::PARK, list_instances_waves: whole generations of pixels on the resident lanes decide).  800 x 800
+    pixels take the five-wave build, a quarter of the rows (stripes of four ranks) the four-wave one: same frame, same rays."""
+    w = h = 800
+    s = rt.builtin_scene(7, 0, w, h)
+    film = rt.Film(w, h)
+    st = film.render(s, 3, variant=variant)
+    full = film.download().copy()
+    assert st.kernel_vgprs <= 96, st.kernel_vgprs
+    world, rays, parts = 4, 0, []
+    rows_max = max(len(rt.stripe_rows(h, 8, r, world)) for r in range(world))
+    for r in range(world):
+        part = rt.Film(w, h, stripe_rows=8, rank=r, world_size=world)
+        pst = part.render(s, 3, variant=variant)
+        assert 96 < pst.kernel_vgprs <= 128, pst.kernel_vgprs
+        rays += pst.rays
+        mine = part.download()[rt.stripe_rows(h, 8, r, world)]
+        buf = np.zeros(rows_max * w * 3)
+        buf[: mine.size] = mine.ravel()
+        parts.append(buf)
+    out = rt.deinterleave(np.stack(parts), w, h, 8, world)
+    assert np.array_equal(out.view(np.uint64), full.view(np.uint64))
+    assert rays == st.rays
+
+
 def test_progressive_state_is_saved_and_resumed():
     """randState is written back (R/kernel.cu:146): 2 spp then 2 more spp continues the same streams."""
     s = rt.builtin_scene(10, 0, 32, 16)

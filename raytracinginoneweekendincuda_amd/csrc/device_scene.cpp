@@ -230,20 +230,6 @@ int rt_scene_upload(rt_scene *scene, int device)
     up(f.quads, d.quads);
     up(f.quad_aa, d.quad_aa);
     up(f.boxes, d.boxes);
-    {
-        // render.hip box_closest: m = 2^-30 (|mn| + |mx|) per axis; in = [mn + m, mx - m], out = [mn - m, mx + m]
-        std::vector<BoxBounds> bounds(f.boxes.size());
-        for (size_t k = 0; k < bounds.size(); k++)
-            for (int a = 0; a < 3; a++) {
-                const double mn = f.boxes[k].mn[a], mx = f.boxes[k].mx[a];
-                const double m = 9.313225746154785e-10 * (std::fabs(mn) + std::fabs(mx));
-                bounds[k].in_lo[a] = mn + m;
-                bounds[k].in_hi[a] = mx - m;
-                bounds[k].out_lo[a] = mn - m;
-                bounds[k].out_hi[a] = mx + m;
-            }
-        up(bounds, d.box_bounds);
-    }
     up(f.quad_mat, d.quad_mat);
     up(f.objects, d.objects);
     up(f.items, d.items);

@@ -56,9 +56,7 @@ struct AAQuad { double na, d, wa, qp, qq, ku, kv; uint32_t code, pad; };  // cod
 // than 2^-30 of the coordinates' magnitude is accepted, one that is outside by as much is rejected, and only the
 // sliver in between evaluates the face's own alpha / beta (render.hip box_closest has the bound).
 struct BoxRec { double na[6], d[6], mn[3], mx[3]; uint32_t quad_first, pad; };
-// The four bounds of that sliver, worked out once per box instead of once per ray (device_scene.cpp): list-world kernels read them
-// through scalar loads -- every lane is on the same box -- and compare against them straight from scalar registers.
-struct BoxBounds { double in_lo[3], in_hi[3], out_lo[3], out_hi[3]; };
+
 
 // Instance transform step (R/Instance.h:31-37 Translate, :74-112 RotateY).
 enum : uint32_t { XF_TRANSLATE = 0u, XF_ROTATE_Y = 1u };
@@ -193,7 +191,6 @@ struct DeviceScene {
     const QuadGeom *quads;
     const AAQuad *quad_aa;        // parallel to quads
     const BoxRec *boxes;
-    const BoxBounds *box_bounds;  // one per box
     const uint32_t *quad_mat;
     const ObjectRec *objects;
     const uint32_t *items;        // GEOM_MIXED entries (prim refs)

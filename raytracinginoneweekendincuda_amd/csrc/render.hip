@@ -334,11 +334,8 @@ DEV bool quad_test_at(const DeviceScene &sc, uint32_t idx, const Ray &r, double 
 //   mn[p] + m <= P[p] <= mx[p] - m  =>  2^-30 <= (P[p] - Q[p]) / u[p] <= 1 - 2^-31  =>  alpha in [0, 1] for certain;
 //   P[p] < mn[p] - m or P[p] > mx[p] + m  =>  alpha < 0 or alpha > 1 for certain;
 // the same for beta along q.  Only a hit point inside the 2m sliver around an edge needs alpha / beta themselves.
-// PRE: the sliver's bounds come from the host's table (BoxBounds) through scalar loads -- list-world kernels, where `box` is
-// the same for every lane; otherwise they are computed here from the box's corners.
-template <bool PRE = false>
 DEV bool box_closest(const DeviceScene &sc, const BoxRec &bx, const Ray &r, double tmin, double tmax, double &t_best,
-                     uint32_t &ref_best, [[maybe_unused]] uint32_t box = 0u)
+                     uint32_t &ref_best)
 {
     double t[6];
     bool ok[6];
@@ -348,19 +345,11 @@ DEV bool box_closest(const DeviceScene &sc, const BoxRec &bx, const Ray &r, doub
     ok[3] = aa_plane<0>(bx.na[3], bx.d[3], r, tmin, tmax, t[3]);  // left
     ok[4] = aa_plane<1>(bx.na[4], bx.d[4], r, tmin, tmax, t[4]);  // top
     ok[5] = aa_plane<1>(bx.na[5], bx.d[5], r, tmin, tmax, t[5]);  // bottom
-    Vec in_lo, in_hi, out_lo, out_hi;
-    if constexpr (PRE) {
-        const RT_CONST double *bb = const_doubles(sc.box_bounds + box);
-        in_lo = mk(bb[0], bb[1], bb[2]);
-        in_hi = mk(bb[3], bb[4], bb[5]);
-        out_lo = mk(bb[6], bb[7], bb[8]);
-        out_hi = mk(bb[9], bb[10], bb[11]);
-    } else {
-        const Vec mn = mk(bx.mn[0], bx.mn[1], bx.mn[2]), mx = mk(bx.mx[0], bx.mx[1], bx.mx[2]);
-        const double k30 = 9.313225746154785e-10;  // 2^-30
-        const Vec m = mk(k30 * (fabs(mn.x) + fabs(mx.x)), k30 * (fabs(mn.y) + fabs(mx.y)), k30 * (fabs(mn.z) + fabs(mx.z)));
-        in_lo = mn + m; in_hi = mx - m; out_lo = mn - m; out_hi = mx + m;
-    }
+    const Vec mn = mk(bx.mn[0], bx.mn[1], bx.mn[2]), mx = mk(bx.mx[0], bx.mx[1], bx.mx[2]);
+    const double k30 = 9.313225746154785e-10;  // 2^-30
+    const Vec m = mk(k30 * (fabs(mn.x) + fabs(mx.x)), k30 * (fabs(mn.y) + fabs(mx.y)), k30 * (fabs(mn.z) + fabs(mx.z)));
+    // (the four bounds from a host-made table through scalar loads instead: measured 1-3 % slower, four and five waves per SIMD)
+    const Vec in_lo = mn + m, in_hi = mx - m, out_lo = mn - m, out_hi = mx + m;
     const uint32_t quad_first = bx.quad_first;
     double closest = tmax;
     bool any = false;
@@ -511,7 +500,6 @@ DEV bool subbvh_closest(const DeviceScene &sc, uint32_t root, const Ray &lr, dou
 }
 
 // Closest hit over a composite leaf's geometry (R/HittableList.h:39-57 for groups).
-template <bool UNIFORM = false>  // every lane is on the same object (list-world kernels)
 DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, double tmin, double tmax,
                       double &t_best, uint32_t &ref_best)
 {
@@ -552,7 +540,7 @@ DEV bool geom_closest(const DeviceScene &sc, const ObjectRec &o, const Ray &lr, 
         }
         break;
     case GEOM_BOX:
-        any = box_closest<UNIFORM>(sc, get_box(sc, o.first), lr, tmin, tmax, closest, ref_best, o.first);
+        any = box_closest(sc, get_box(sc, o.first), lr, tmin, tmax, closest, ref_best);
         break;
     case GEOM_QUADS:
         for (uint32_t k = 0; k < o.count; k++) {
@@ -629,7 +617,7 @@ DEV bool object_span(const DeviceScene &sc, uint32_t oi, const Ray &r, double tm
             const double hi = medium ? DBL_MAX : tmax;
             double t;
             PH_SUB_BEGIN();
-            const bool got = geom_closest<T::WORLD == 1 && !T::GROUPED>(sc, o, lr, lo, hi, t, pref);
+            const bool got = geom_closest(sc, o, lr, lo, hi, t, pref);
 #if RT_PHASES
             asm volatile("" ::"v"(t));
 #endif
@@ -883,7 +871,7 @@ DEV bool leaf_test(const DeviceScene &sc, uint32_t ref, const Ray &r, double a, 
             PH_SUB_BEGIN();
             double t;
             uint32_t face = kNone;
-            const bool found = box_closest<T::WORLD == 1 && !T::GROUPED>(sc, get_box(sc, ref & kRefIndexMask), r, tmin, tmax, t, face, ref & kRefIndexMask);
+            const bool found = box_closest(sc, get_box(sc, ref & kRefIndexMask), r, tmin, tmax, t, face);
             if (found) {
                 best.t = t;
                 best.ref = face;

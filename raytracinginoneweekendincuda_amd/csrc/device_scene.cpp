@@ -599,8 +599,12 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
         }
         HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, (light) queue cursor
         if (split) {
-            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", sphere_list_kernel ? 10 : 12, 1, 1 << 20);
-            int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6, 1, 64);
+            // (r3) sphere lists: 12 rays per sample and four pixels per serving wave.  With eight the frame time was bimodal -- six
+            // frames in one call: 188...246 ms, mean 209 -- because the serving wave that happens to hold the longest chains sets
+            // it; with four (16 lanes per ray) the mean is 188.5 ms and the spread 186...192.  Earlier sweeps took the best of two
+            // runs per setting and did not see it (profiles/r03_c2_serving_sweep.txt).
+            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", 12, 1, 1 << 20);
+            int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? 4 : 6, 1, 64);
             const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
             // the serving waves' rays are the frame's critical path
             const int heavy_prio = tune("RTOW_HEAVY_PRIO", (sphere_list_kernel && roles_in_one_launch) ? 3 : 0, 0, 3);

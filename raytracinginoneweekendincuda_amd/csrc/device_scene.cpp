@@ -3,6 +3,7 @@
 // timing.  Replaces the host driver section R/kernel.cu:675-691.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -133,7 +134,8 @@ struct FilmImpl {
     uint32_t *tile_cost = nullptr, *tile_order = nullptr;  // per 8x8 tile of this rank's rows: probed rays, and the tiles ranked by them
     // sphere-list worlds, heavy / light pixels (allocated on first use): probed rays per pixel, the heavy pixels' list and
     // count, every pixel's class; the heavy launch runs on its own stream beside the light one
-    uint32_t *pix_cost = nullptr, *heavy_list = nullptr, *heavy_count = nullptr;
+    uint32_t *pix_cost = nullptr, *heavy_list = nullptr, *heavy_count = nullptr, *super_list = nullptr;  // heavy_count[1]: length of super_list
+    uint32_t *dbg_times = nullptr;  // RT_STAMP diagnostic builds (RTOW_PRINT_TAIL)
     uint8_t *pix_class = nullptr;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_aux[2] = {nullptr, nullptr};
@@ -382,8 +384,10 @@ void rt_film_destroy(rt_film *film)
     if (f->tile_cost) hipFree(f->tile_cost);
     if (f->tile_order) hipFree(f->tile_order);
     if (f->pix_cost) hipFree(f->pix_cost);
+    if (f->dbg_times) hipFree(f->dbg_times);
     if (f->heavy_list) hipFree(f->heavy_list);
     if (f->heavy_count) hipFree(f->heavy_count);
+    if (f->super_list) hipFree(f->super_list);
     if (f->pix_class) hipFree(f->pix_class);
     for (int k = 0; k < 2; k++)
         if (f->ev_aux[k]) hipEventDestroy(f->ev_aux[k]);
@@ -565,10 +569,15 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
     if (ra.pixels_per_wave < 64 && list_scan_kernel)  // the instantiation that deals leaves to lanes: report that one
         HIP_TRY(p->variant ? kernel_info_fast(ds, ra, &f.last_kernel) : kernel_info_strict(ds, ra, &f.last_kernel));
 
+    if (tune_set("RTOW_PRINT_TAIL")) {  // diagnostic builds (-DRT_STAMP=1 -DRT_TUNING=1)
+        if (!f.dbg_times) HIP_TRY(hipMalloc((void **)&f.dbg_times, (size_t)f.n_pixels * 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(f.dbg_times, 0, (size_t)f.n_pixels * 2 * sizeof(uint32_t), stream));
+        ra.dbg_times = f.dbg_times;
+    }
     if (rank_tiles || split) {
         // sphere-list frames of 400 samples and more rehearse 8: the heavy pixels are told apart more reliably (C2, three
         // interleaved pairs in one call: 1859-1893 with 4, 1908-1918 with 8; the primitive-BVH kernel is better off with 4)
-        int probe_spp = split ? ((sphere_list_kernel && p->samples_per_pixel >= 400) ? 8 : 4) : p->samples_per_pixel / 100;
+        int probe_spp = split ? (p->samples_per_pixel >= 400 ? 8 : 4) : p->samples_per_pixel / 100;  // (r3: 8 for the BVH kernel too, with the settings below)
         probe_spp = probe_spp < 1 ? 1 : (probe_spp > 8 ? 8 : probe_spp);
         probe_spp = tune("RTOW_PROBE_SPP", probe_spp, 1, 64);
         if (probe_spp > p->samples_per_pixel) probe_spp = p->samples_per_pixel;
@@ -603,21 +612,36 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             // frames in one call: 188...246 ms, mean 209 -- because the serving wave that happens to hold the longest chains sets
             // it; with four (16 lanes per ray) the mean is 188.5 ms and the spread 186...192.  Earlier sweeps took the best of two
             // runs per setting and did not see it (profiles/r03_c2_serving_sweep.txt).
-            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", 12, 1, 1 << 20);
+            // primitive BVH worlds (r3): 9 rays per sample, three serving waves per workgroup, and the longest chains of all -- 30 rays
+            // per sample and more -- one to a wave (super_list below).  Every light pixel just under the threshold runs at a light
+            // wave's 30 us per ray from the first millisecond to the frame's last (per-pixel stamps, RTOW_PRINT_TAIL), so the
+            // threshold, the serving capacity and the longest heavy chain have to be moved together: C3 162 -> 153 ms, means of
+            // four frames per setting in one call (profiles/r03_c3_serving_sweep.txt).
+            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", sphere_list_kernel ? 12 : 9, 1, 1 << 20);
             int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? 4 : 6, 1, 64);
             const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
             // the serving waves' rays are the frame's critical path
             const int heavy_prio = tune("RTOW_HEAVY_PRIO", (sphere_list_kernel && roles_in_one_launch) ? 3 : 0, 0, 3);
             HIP_TRY(hipMemsetAsync(f.heavy_count, 0, 64, stream));
+            // the longest chains of all get a serving wave each (RenderArgs::super_list): BVH worlds, whose serving waves walk one lane per ray
+            const int super_rays = tune("RTOW_SUPER_RAYS", (!sphere_list_kernel && roles_in_one_launch) ? 30 : 0, 0, 1 << 20);
+            const bool longest = roles_in_one_launch && super_rays > 0;
+            if (longest && !f.super_list) HIP_TRY(hipMalloc((void **)&f.super_list, (size_t)f.n_pixels * sizeof(uint32_t)));
             HIP_TRY(launch_classify_pixels(f.pix_cost, f.n_pixels, (uint32_t)(heavy_rays_per_sample * probe_spp), f.pix_class,
-                                           f.heavy_list, f.heavy_count, stream));
+                                           f.heavy_list, f.heavy_count, stream, longest ? f.super_list : nullptr, (uint32_t)(super_rays * probe_spp)));
+            if (longest) {
+                HIP_TRY(hipMemsetAsync(f.ray_counter + 9, 0, sizeof(unsigned long long), stream));
+                ra.super_list = f.super_list;
+                ra.super_count = f.heavy_count + 1;
+                ra.super_cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 9);
+            }
             HIP_TRY(hipMemsetAsync(f.ray_counter + 6, 0, sizeof(unsigned long long), stream));  // heavy queue cursor
             if (roles_in_one_launch) {
                 if (sphere_list_kernel && ra.max_blocks_per_cu <= 0) ra.max_blocks_per_cu = 3;
                 ra.heavy_list = f.heavy_list;
                 ra.heavy_count = f.heavy_count;
                 ra.heavy_cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
-                ra.heavy_waves = tune("RTOW_HEAVY_WAVES", 2, 0, 12);
+                ra.heavy_waves = tune("RTOW_HEAVY_WAVES", sphere_list_kernel ? 2 : 3, 0, 12);
                 ra.heavy_ppw = heavy_ppw;
                 ra.heavy_priority = heavy_prio;
                 ra.pix_class = f.pix_class;
@@ -715,6 +739,32 @@ int rt_render_finish(rt_scene *scene, rt_film *film, rt_render_stats *stats)
             std::fprintf(stderr, "heavy pixels %u of %u; probe rays per pixel: max %u; histogram by 16:", n_heavy, f.n_pixels, top);
             for (int k = 0; k < 16; k++) std::fprintf(stderr, " %llu", hist[k]);
             std::fprintf(stderr, "\n");
+        }
+        if (tune_set("RTOW_PRINT_TAIL") && f.dbg_times) {  // who finishes last: the 24 last pixels and a histogram of the ends
+            std::vector<uint32_t> t((size_t)f.n_pixels * 2), cost(f.n_pixels, 0);
+            HIP_TRY(hipMemcpy(t.data(), f.dbg_times, t.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (f.pix_cost) HIP_TRY(hipMemcpy(cost.data(), f.pix_cost, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            const uint32_t t0 = (uint32_t)f.host_counters[5];
+            std::vector<uint32_t> order(f.n_pixels);
+            for (uint32_t k = 0; k < f.n_pixels; k++) order[k] = k;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (uint32_t)(t[2 * a + 1] - t0) > (uint32_t)(t[2 * b + 1] - t0); });
+            const double last = (uint32_t)(t[2 * order[0] + 1] - t0) * 1e-5;
+            unsigned long long hist[12] = {};
+            double mean_dur[12] = {}, mean_cost[12] = {};
+            for (uint32_t k = 0; k < f.n_pixels; k++) {
+                const double end = (uint32_t)(t[2 * k + 1] - t0) * 1e-5, dur = (uint32_t)(t[2 * k + 1] - t[2 * k]) * 1e-5;
+                int b = (int)((last - end) / 5.0);
+                b = b > 11 ? 11 : b;
+                hist[b]++; mean_dur[b] += dur; mean_cost[b] += cost[k];
+            }
+            std::fprintf(stderr, "tail: last pixel ends +%.1f ms; pixels ending in the last 5 ms steps (count, mean duration ms, mean probe rays):", last);
+            for (int b = 0; b < 12; b++) std::fprintf(stderr, " [%llu %.1f %.1f]", hist[b], hist[b] ? mean_dur[b] / hist[b] : 0.0, hist[b] ? mean_cost[b] / hist[b] : 0.0);
+            std::fprintf(stderr, "\n");
+            for (int k = 0; k < 24; k++) {
+                const uint32_t px = order[k * 40];
+                std::fprintf(stderr, "  pixel row %u col %u: start +%.1f end +%.1f ms, probe rays %u\n", px / (uint32_t)f.width, px % (uint32_t)f.width,
+                             (uint32_t)(t[2 * px] - t0) * 1e-5, (uint32_t)(t[2 * px + 1] - t0) * 1e-5, cost[px]);
+            }
         }
         if (tune_set("RTOW_PRINT_STAMPS")) {  // diagnostic builds (-DRT_STAMP=1): 100 MHz wall-clock ticks
             const unsigned long long *st = f.host_counters;

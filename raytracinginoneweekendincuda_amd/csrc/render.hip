@@ -2950,6 +2950,9 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     bool heavy_mode = a.heavy_list != nullptr && (int)(threadIdx.x >> 6) < a.heavy_waves;
     bool heavy_dry = false;
     const uint32_t heavy_total = heavy_mode ? *(const RT_CONST uint32_t *)(uintptr_t)a.heavy_count : 0u;
+    const uint32_t super_total = (heavy_mode && a.super_list) ? *(const RT_CONST uint32_t *)(uintptr_t)a.super_count : 0u;
+    bool solo_phase = heavy_mode && a.super_list != nullptr;  // this wave still looks at the list of the longest chains first (RenderArgs::super_list)
+    bool solo_hold = false;  // ... and holds one of them: no other pixel joins it
     if (heavy_mode) {
         if (a.heavy_priority == 1) __builtin_amdgcn_s_setprio(1);
         else if (a.heavy_priority == 2) __builtin_amdgcn_s_setprio(2);
@@ -3005,22 +3008,25 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
         }
 
         const bool from_list = heavy_mode && !heavy_dry;  // this refill takes heavy pixels off the list
-        if (!exhausted && !boost && (!heavy_mode || from_list)) {
+        if (solo_hold && !__any(active)) solo_hold = false;
+        if (!exhausted && !boost && (!heavy_mode || from_list) && !solo_hold) {
             unsigned long long need = __ballot(!active);
             // pixels_per_wave < 64: only the first lanes take pixels.  Sphere-list kernel: the others lend themselves to the
             // grouped scan; BVH kernels: the few rays have the wave's phases to themselves (shorter chain per pixel).
-            const int ppw = from_list ? a.heavy_ppw : a.pixels_per_wave;
+            const bool from_super = from_list && solo_phase;  // one of the longest chains, alone in this wave until it is done
+            const int ppw = from_super ? 1 : (from_list ? a.heavy_ppw : a.pixels_per_wave);
             if (ppw < 64) need &= (1ull << ppw) - 1ull;
             if (need) {
                 PH_BEGIN();
                 [[maybe_unused]] const bool ph_was_idle = !active;
                 const uint32_t cnt = (uint32_t)__popcll(need);
-                const uint32_t queue_len = from_list ? heavy_total : total_slots;
+                const uint32_t queue_len = from_super ? super_total : (from_list ? heavy_total : total_slots);
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(from_list ? a.heavy_cursor : a.cursor, cnt);
+                if (lane == 0) base = atomicAdd(from_super ? a.super_cursor : (from_list ? a.heavy_cursor : a.cursor), cnt);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base + cnt >= queue_len) {
-                    if (from_list) heavy_dry = true;
+                    if (from_super) solo_phase = false;
+                    else if (from_list) heavy_dry = true;
                     else exhausted = true;
                 }
 #if RT_STAMP
@@ -3035,7 +3041,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                     int lr = (int)((tile / tiles_x) * 8u + (w >> 3));
                     bool take = pi < a.width && lr < a.rows_owned;
                     if (a.pixel_list || from_list) {  // listed pixels: compact index -> row, column
-                        const uint32_t loc = from_list ? a.heavy_list[slot] : a.pixel_list[slot];
+                        const uint32_t loc = from_super ? a.super_list[slot] : (from_list ? a.heavy_list[slot] : a.pixel_list[slot]);
                         lr = (int)(loc / (uint32_t)a.width);
                         pi = (int)(loc % (uint32_t)a.width);
                         tile = ((uint32_t)lr >> 3) * tiles_x + ((uint32_t)pi >> 3);
@@ -3064,6 +3070,9 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                         if (RT_PROBE_ON) my_tile = tile;
                         ray = camera_ray(cam, i, j, a.width, a.height, rng);
                         active = true;
+#if RT_STAMP
+                        if (a.dbg_times && !a.probe) a.dbg_times[2 * local] = (uint32_t)wall_clock64();
+#endif
                         if constexpr (T::PARK) {
                             park_put_int<T::BLOCK>(sc.lds_park, 0, (uint32_t)i);
                             park_put_int<T::BLOCK>(sc.lds_park, 1, (uint32_t)j);
@@ -3084,6 +3093,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                         }
                     }
                 }
+                if (from_super && __any(active)) solo_hold = true;
                 PH_END(3, ph_was_idle && active);
             }
         }
@@ -3371,6 +3381,9 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
                     active = false;
                 } else {
                     // R/kernel.cu:146-153: save the RNG state, average, gamma 2
+#if RT_STAMP
+                    if (a.dbg_times) a.dbg_times[2 * local + 1] = (uint32_t)wall_clock64();
+#endif
                     if constexpr (T::PARK) local = (size_t)park_get_int<T::BLOCK>(sc.lds_park, 2);
                     a.state[0 * (size_t)a.n_pixels + local] = rng.d;
                     a.state[1 * (size_t)a.n_pixels + local] = rng.v0;
@@ -3483,21 +3496,23 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, 
 }
 
 __global__ __launch_bounds__(256) void classify_pixels_kernel(const uint32_t *cost, uint32_t n, uint32_t threshold, uint8_t *klass,
-                                                               uint32_t *list, uint32_t *count)
+                                                               uint32_t *list, uint32_t *count, uint32_t *super_list, uint32_t super_threshold)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const bool heavy = cost[k] >= threshold;
+    const bool longest = heavy && super_list && cost[k] >= super_threshold;
     klass[k] = heavy ? 1 : 0;
-    if (heavy) list[atomicAdd(count, 1u)] = k;  // order within the list is irrelevant: every listed pixel starts at once
+    if (longest) super_list[atomicAdd(count + 1, 1u)] = k;
+    else if (heavy) list[atomicAdd(count, 1u)] = k;  // order within the list is irrelevant: every listed pixel starts at once
 }
 
 hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, uint32_t threshold, uint8_t *pix_class, uint32_t *list,
-                                  uint32_t *count, hipStream_t stream)
+                                  uint32_t *count, hipStream_t stream, uint32_t *super_list, uint32_t super_threshold)
 {
     if (n_pixels == 0) return hipSuccess;
     hipLaunchKernelGGL(classify_pixels_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, pix_cost, n_pixels, threshold,
-                       pix_class, list, count);
+                       pix_class, list, count, super_list, super_threshold);
     return hipGetLastError();
 }
 

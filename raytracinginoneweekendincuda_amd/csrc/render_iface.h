@@ -34,6 +34,7 @@ struct RenderArgs {
     // pix_cost; classify_pixels marks the heavy ones in pix_class and lists them; the frame is then two launches -- the
     // listed pixels (pixel_list, a few lanes-per-ray waves, started first) and all the others (pix_class != 0 is skipped).
     uint32_t *pix_cost;               // probe launches: rays traced by each owned pixel
+    uint32_t *dbg_times;              // RT_STAMP builds: per pixel, low words of the wall clock at its start and at its end
     const uint32_t *pixel_list;       // render launch over a list of owned pixels (compact indices) instead of the tile queue
     const uint32_t *pixel_list_count; // device word holding the length of pixel_list
     const uint8_t *pix_class;         // tile-queue launches: pixels whose class is non-zero belong to another launch
@@ -43,6 +44,12 @@ struct RenderArgs {
     // heavy_cursor) and join the tile queue when the list is done; the tile queue skips pix_class != 0 as above.
     const uint32_t *heavy_list;
     const uint32_t *heavy_count;
+    // ... the very longest chains among them (classify_pixels: probed cost >= super_threshold) on a list of their own, which the
+    // serving waves take from first, ONE pixel per wave and nothing beside it until it is done: the frame cannot end before that
+    // pixel does, and alone in its wave its rays take two thirds of the time they take with five neighbours
+    const uint32_t *super_list;
+    const uint32_t *super_count;
+    uint32_t *super_cursor;
     uint32_t *heavy_cursor;
     int32_t heavy_waves, heavy_ppw, heavy_priority;
     uint32_t n_pixels;
@@ -89,9 +96,10 @@ hipError_t kernel_info_strict(const DeviceScene &sc, const RenderArgs &a, Kernel
 hipError_t kernel_info_fast(const DeviceScene &sc, const RenderArgs &a, KernelInfo *info);
 
 // class 1 + an entry in `list` (its length in *count, which the caller has zeroed) for every pixel whose probed cost is at
-// least `threshold` rays, class 0 for the others
+// least `threshold` rays, class 0 for the others; with super_list: the pixels of at least super_threshold rays go there instead
+// (length count[1])
 hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, uint32_t threshold, uint8_t *pix_class, uint32_t *list,
-                                  uint32_t *count, hipStream_t stream);
+                                  uint32_t *count, hipStream_t stream, uint32_t *super_list = nullptr, uint32_t super_threshold = 0);
 
 // tile_order[k] = the tile with the k-th highest cost (counting sort over 256 cost classes; one workgroup)
 // (flat_x8 / 8 = ratio of the heaviest tile to the mean below which the row-major order is kept)

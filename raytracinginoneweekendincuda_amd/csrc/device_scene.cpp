@@ -617,14 +617,17 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             // wave's 30 us per ray from the first millisecond to the frame's last (per-pixel stamps, RTOW_PRINT_TAIL), so the
             // threshold, the serving capacity and the longest heavy chain have to be moved together: C3 162 -> 153 ms, means of
             // four frames per setting in one call (profiles/r03_c3_serving_sweep.txt).
-            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", sphere_list_kernel ? 12 : 9, 1, 1 << 20);
-            int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? 4 : 6, 1, 64);
+            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", (sphere_list_kernel && !roles_in_one_launch) ? 12 : 9, 1, 1 << 20);
+            int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6, 1, 64);
             const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
             // the serving waves' rays are the frame's critical path
             const int heavy_prio = tune("RTOW_HEAVY_PRIO", (sphere_list_kernel && roles_in_one_launch) ? 3 : 0, 0, 3);
             HIP_TRY(hipMemsetAsync(f.heavy_count, 0, 64, stream));
             // the longest chains of all get a serving wave each (RenderArgs::super_list): BVH worlds, whose serving waves walk one lane per ray
-            const int super_rays = tune("RTOW_SUPER_RAYS", (!sphere_list_kernel && roles_in_one_launch) ? 30 : 0, 0, 1 << 20);
+            // sphere lists, two tiers: from 12 rays per sample four pixels to a serving wave (16 lanes per ray), from 9 eight (8 lanes):
+            // a pixel of 10 rays per sample takes 200 ms in a light wave -- the whole frame -- and 50 ms in a serving wave
+            // (C2, five frames per setting in one call: 198.6 -> 190.5 ms; threshold 8: 194, 7: 201; profiles/r03_c2_serving_sweep.txt)
+            const int super_rays = tune("RTOW_SUPER_RAYS", roles_in_one_launch ? (sphere_list_kernel ? 12 : 30) : 0, 0, 1 << 20);
             const bool longest = roles_in_one_launch && super_rays > 0;
             if (longest && !f.super_list) HIP_TRY(hipMalloc((void **)&f.super_list, (size_t)f.n_pixels * sizeof(uint32_t)));
             HIP_TRY(launch_classify_pixels(f.pix_cost, f.n_pixels, (uint32_t)(heavy_rays_per_sample * probe_spp), f.pix_class,
@@ -634,6 +637,7 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
                 ra.super_list = f.super_list;
                 ra.super_count = f.heavy_count + 1;
                 ra.super_cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 9);
+                ra.super_ppw = tune("RTOW_SUPER_PPW", sphere_list_kernel ? 4 : 1, 1, 64);
             }
             HIP_TRY(hipMemsetAsync(f.ray_counter + 6, 0, sizeof(unsigned long long), stream));  // heavy queue cursor
             if (roles_in_one_launch) {

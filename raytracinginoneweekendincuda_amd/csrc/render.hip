@@ -3014,7 +3014,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             // pixels_per_wave < 64: only the first lanes take pixels.  Sphere-list kernel: the others lend themselves to the
             // grouped scan; BVH kernels: the few rays have the wave's phases to themselves (shorter chain per pixel).
             const bool from_super = from_list && solo_phase;  // one of the longest chains, alone in this wave until it is done
-            const int ppw = from_super ? 1 : (from_list ? a.heavy_ppw : a.pixels_per_wave);
+            const int ppw = from_super ? a.super_ppw : (from_list ? a.heavy_ppw : a.pixels_per_wave);
             if (ppw < 64) need &= (1ull << ppw) - 1ull;
             if (need) {
                 PH_BEGIN();

@@ -648,6 +648,11 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
                 ra.heavy_waves = tune("RTOW_HEAVY_WAVES", sphere_list_kernel ? 2 : 3, 0, 12);
                 ra.heavy_ppw = heavy_ppw;
                 ra.heavy_priority = heavy_prio;
+                // fewer pixels per serving wave than the tuned numbers only where the frame leaves lanes idle anyway -- fewer pixels
+                // than the twelve waves per CU of these kernels hold, i.e. a rank's stripes of a split frame: there a chain is
+                // shortest with its wave to itself (C2 / 8: slowest rank 135 -> 97 ms, C3 / 8: 155 -> 122).  A full frame packs the
+                // serving waves as densely as tuned: the ones left over join the light queue at once (C3 152 against 159 ms).
+                ra.adaptive_ppw = tune("RTOW_ADAPTIVE_PPW", (size_t)f.n_pixels <= (size_t)f.num_cus * 12u * 64u ? 1 : 0, 0, 1);
                 ra.pix_class = f.pix_class;
             } else {
                 HIP_TRY(hipEventRecord(f.ev_aux[0], stream));

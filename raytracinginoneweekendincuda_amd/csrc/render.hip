@@ -2953,6 +2953,27 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     const uint32_t super_total = (heavy_mode && a.super_list) ? *(const RT_CONST uint32_t *)(uintptr_t)a.super_count : 0u;
     bool solo_phase = heavy_mode && a.super_list != nullptr;  // this wave still looks at the list of the longest chains first (RenderArgs::super_list)
     bool solo_hold = false;  // ... and holds one of them: no other pixel joins it
+    // Pixels per serving wave: no more than it takes to start every listed pixel at once (a rank's stripes of a split frame list
+    // few, and a chain is shortest with the wave to itself), at most what the launcher allows; the grouped scan of sphere lists
+    // deals lanes in powers of two.
+    int super_ppw = a.super_ppw, heavy_ppw = a.heavy_ppw;
+    if (heavy_mode && a.adaptive_ppw) {
+        const uint32_t serving = gridDim.x * (uint32_t)a.heavy_waves;
+        auto fit = [&](uint32_t total, int cap) {
+            int p = (int)((total + serving - 1u) / serving);
+            p = p < 1 ? 1 : p;
+            if (T::WORLD == 2) {
+                int q = 1;
+                while (q < p) q *= 2;
+                p = q;
+            }
+            return p > cap ? cap : p;
+        };
+        // (both tiers by the two lists' sum: with the first tier alone in view a full C2 frame would serve it two to a wave and
+        // start the second tier later -- 193 -> 197 ms)
+        super_ppw = fit(super_total + heavy_total, a.super_ppw);
+        heavy_ppw = fit(super_total + heavy_total, a.heavy_ppw);
+    }
     if (heavy_mode) {
         if (a.heavy_priority == 1) __builtin_amdgcn_s_setprio(1);
         else if (a.heavy_priority == 2) __builtin_amdgcn_s_setprio(2);
@@ -3014,7 +3035,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
             // pixels_per_wave < 64: only the first lanes take pixels.  Sphere-list kernel: the others lend themselves to the
             // grouped scan; BVH kernels: the few rays have the wave's phases to themselves (shorter chain per pixel).
             const bool from_super = from_list && solo_phase;  // one of the longest chains, alone in this wave until it is done
-            const int ppw = from_super ? a.super_ppw : (from_list ? a.heavy_ppw : a.pixels_per_wave);
+            const int ppw = from_super ? super_ppw : (from_list ? heavy_ppw : a.pixels_per_wave);
             if (ppw < 64) need &= (1ull << ppw) - 1ull;
             if (need) {
                 PH_BEGIN();

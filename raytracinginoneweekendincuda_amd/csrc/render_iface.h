@@ -50,6 +50,7 @@ struct RenderArgs {
     const uint32_t *super_list;
     const uint32_t *super_count;
     uint32_t *super_cursor;
+    int32_t adaptive_ppw;             // fewer pixels per serving wave where the lists are short (render_kernel: fit)
     int32_t super_ppw;                // pixels of that list per serving wave (1 for BVH walks; sphere lists: 4, the grouped scan's 16 lanes per ray)
     uint32_t *heavy_cursor;
     int32_t heavy_waves, heavy_ppw, heavy_priority;

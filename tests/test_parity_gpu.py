@@ -113,6 +113,21 @@ def test_instanced_list_kernel_on_five_waves_per_simd_gives_the_four_wave_frame(
     assert rays == st.rays
 
 
+@pytest.mark.parametrize("scene_id,world_kind", [(11, 1), (0, 0)])
+def test_a_ranks_stripes_of_the_benchmark_frame_equal_the_full_frames_rows(scene_id, world_kind):
+    """One rank's share of an 8-way split of the 1200 x 800 frame holds fewer pixels than the GPU has lanes: its heavy pixels are
+    served fewer to a wave than in the full frame (RenderArgs::adaptive_ppw, device_scene.cpp).  Same pixels as the full frame's."""
+    w, h, spp, world, rank = 1200, 800, 64, 8, 3
+    s = rt.builtin_scene(scene_id, world_kind, w, h)
+    full = rt.Film(w, h)
+    st_full = full.render(s, spp, variant=0)
+    part = rt.Film(w, h, stripe_rows=8, rank=rank, world_size=world)
+    st_part = part.render(s, spp, variant=0)
+    rows = rt.stripe_rows(h, 8, rank, world)
+    assert st_part.kernel_kind == st_full.kernel_kind
+    assert np.array_equal(part.download()[rows].view(np.uint64), full.download()[rows].view(np.uint64))
+
+
 def test_progressive_state_is_saved_and_resumed():
     """randState is written back (R/kernel.cu:146): 2 spp then 2 more spp continues the same streams."""
     s = rt.builtin_scene(10, 0, 32, 16)

@@ -617,6 +617,10 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             // wave's 30 us per ray from the first millisecond to the frame's last (per-pixel stamps, RTOW_PRINT_TAIL), so the
             // threshold, the serving capacity and the longest heavy chain have to be moved together: C3 162 -> 153 ms, means of
             // four frames per setting in one call (profiles/r03_c3_serving_sweep.txt).
+            // a frame with fewer pixels than the GPU has lanes (a rank's stripes of a split frame) has serving waves to spare.  Lower
+            // thresholds there helped three ranks of eight (profiles/r03_rank_serving_sweep.txt) and cost the rank with the longest
+            // chains a third (C2 96 -> 141 ms, C3 115 -> 148): the thresholds stay, the serving waves take fewer pixels each.
+            const bool underfilled = roles_in_one_launch && (size_t)f.n_pixels <= (size_t)f.num_cus * 12u * 64u;
             const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", (sphere_list_kernel && !roles_in_one_launch) ? 12 : 9, 1, 1 << 20);
             int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6, 1, 64);
             const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
@@ -652,7 +656,7 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
                 // than the twelve waves per CU of these kernels hold, i.e. a rank's stripes of a split frame: there a chain is
                 // shortest with its wave to itself (C2 / 8: slowest rank 135 -> 97 ms, C3 / 8: 155 -> 122).  A full frame packs the
                 // serving waves as densely as tuned: the ones left over join the light queue at once (C3 152 against 159 ms).
-                ra.adaptive_ppw = tune("RTOW_ADAPTIVE_PPW", (size_t)f.n_pixels <= (size_t)f.num_cus * 12u * 64u ? 1 : 0, 0, 1);
+                ra.adaptive_ppw = tune("RTOW_ADAPTIVE_PPW", underfilled ? 1 : 0, 0, 1);
                 ra.pix_class = f.pix_class;
             } else {
                 HIP_TRY(hipEventRecord(f.ev_aux[0], stream));

@@ -528,9 +528,13 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
     // the deep general kernel (one 768-thread workgroup per CU, C5): its ray chains are the longest of all (a ray takes ~140 us
     // in a full wave), which decides the frame whenever a GPU holds few pixels per lane -- a small frame, or one rank's share
     const bool deep_kernel = kind == 7 && f.last_kernel.lds_bytes > 64 * 1024;
-    // Measured and not adopted: with the fixed threshold most of C5's pixels through the mist and the glass count as heavy and
-    // two server waves per workgroup take ten times as long over them (1/8 of the frame at 200 spp: 789 -> 1900 ms).
-    const bool deep_roles = deep_kernel && tune("RTOW_ROLES_DEEP", 0, 0, 1) != 0;
+    // (r3) Heavy and light pixels for this kernel too -- where the frame is a few generations of pixels on the GPU's lanes, i.e. a
+    // rank's stripes of a split frame.  C5 at 200 spp, one rank of N rendered alone: 699 / 712 / 646 / 597 / 709 / 479 ms for
+    // N = 2 / 3 / 4 / 6 / 8 / 16 without classes -- no scaling at all, every rank waits for its longest chains -- and
+    // 737 / 566 / 447 / 395 / 368 / 302 ms with them (profiles/r03_c5_roles.txt).  A whole frame (13 generations) is throughput
+    // and loses by them (1030 -> 1400 ms and worse), as it did in r2 with other settings; so: up to five generations.
+    const double generations = (double)f.n_pixels / ((double)f.num_cus * 12.0 * 64.0);
+    const bool deep_roles = deep_kernel && tune("RTOW_ROLES_DEEP", generations <= 5.0 ? 1 : 0, 0, 1) != 0;
     const bool ppw_given = (p->pixels_per_wave > 0 && p->pixels_per_wave < 64) || tune_set("RTOW_PIXELS_PER_WAVE");
     bool split = (sphere_list_kernel || prim_bvh_kernel || deep_roles) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
                  f.n_pixels >= 65536u && !ppw_given;
@@ -621,8 +625,8 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             // thresholds there helped three ranks of eight (profiles/r03_rank_serving_sweep.txt) and cost the rank with the longest
             // chains a third (C2 96 -> 141 ms, C3 115 -> 148): the thresholds stay, the serving waves take fewer pixels each.
             const bool underfilled = roles_in_one_launch && (size_t)f.n_pixels <= (size_t)f.num_cus * 12u * 64u;
-            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", (sphere_list_kernel && !roles_in_one_launch) ? 12 : 9, 1, 1 << 20);
-            int heavy_ppw = tune("RTOW_HEAVY_PPW", sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6, 1, 64);
+            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", deep_roles ? (generations <= 2.2 ? 14 : 20) : ((sphere_list_kernel && !roles_in_one_launch) ? 12 : 9), 1, 1 << 20);
+            int heavy_ppw = tune("RTOW_HEAVY_PPW", deep_roles ? 12 : (sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6), 1, 64);
             const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
             // the serving waves' rays are the frame's critical path
             const int heavy_prio = tune("RTOW_HEAVY_PRIO", (sphere_list_kernel && roles_in_one_launch) ? 3 : 0, 0, 3);
@@ -631,7 +635,7 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             // sphere lists, two tiers: from 12 rays per sample four pixels to a serving wave (16 lanes per ray), from 9 eight (8 lanes):
             // a pixel of 10 rays per sample takes 200 ms in a light wave -- the whole frame -- and 50 ms in a serving wave
             // (C2, five frames per setting in one call: 198.6 -> 190.5 ms; threshold 8: 194, 7: 201; profiles/r03_c2_serving_sweep.txt)
-            const int super_rays = tune("RTOW_SUPER_RAYS", roles_in_one_launch ? (sphere_list_kernel ? 12 : 30) : 0, 0, 1 << 20);
+            const int super_rays = tune("RTOW_SUPER_RAYS", (roles_in_one_launch && !deep_roles) ? (sphere_list_kernel ? 12 : 30) : 0, 0, 1 << 20);
             const bool longest = roles_in_one_launch && super_rays > 0;
             if (longest && !f.super_list) HIP_TRY(hipMalloc((void **)&f.super_list, (size_t)f.n_pixels * sizeof(uint32_t)));
             HIP_TRY(launch_classify_pixels(f.pix_cost, f.n_pixels, (uint32_t)(heavy_rays_per_sample * probe_spp), f.pix_class,
@@ -649,7 +653,7 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
                 ra.heavy_list = f.heavy_list;
                 ra.heavy_count = f.heavy_count;
                 ra.heavy_cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
-                ra.heavy_waves = tune("RTOW_HEAVY_WAVES", sphere_list_kernel ? 2 : 3, 0, 12);
+                ra.heavy_waves = tune("RTOW_HEAVY_WAVES", deep_roles ? (generations <= 2.2 ? 6 : 4) : (sphere_list_kernel ? 2 : 3), 0, 12);
                 ra.heavy_ppw = heavy_ppw;
                 ra.heavy_priority = heavy_prio;
                 // fewer pixels per serving wave than the tuned numbers only where the frame leaves lanes idle anyway -- fewer pixels

@@ -128,6 +128,25 @@ def test_a_ranks_stripes_of_the_benchmark_frame_equal_the_full_frames_rows(scene
     assert np.array_equal(part.download()[rows].view(np.uint64), full.download()[rows].view(np.uint64))
 
 
+def test_final_scene_rank_stripes_with_pixel_classes_equal_the_full_frames_rows(earth):
+    """C5's kernel serves heavy and light pixels by wave where the frame is a few generations of pixels on the GPU's lanes -- one
+    rank's stripes of an 8-way split -- and not for the whole frame (device_scene.cpp deep_roles).  Same pixels either way, and the
+    media's random draws with them."""
+    w, h, spp, world, rank = 1600, 1600, 64, 8, 4
+    s = rt.builtin_scene(9, 0, w, h, earth=earth)
+    full = rt.Film(w, h)
+    st_full = full.render(s, spp, variant=0)
+    part = rt.Film(w, h, stripe_rows=8, rank=rank, world_size=world)
+    st_part = part.render(s, spp, variant=0)
+    rows = rt.stripe_rows(h, 8, rank, world)
+    assert st_part.kernel_kind == st_full.kernel_kind == 263
+    assert np.array_equal(part.download()[rows].view(np.uint64), full.download()[rows].view(np.uint64))
+    plain = rt.Film(w, h, stripe_rows=8, rank=rank, world_size=world)
+    st_plain = plain.render(s, spp, variant=0, flags=64)   # RT_FLAG_NO_PIXEL_CLASSES
+    assert st_plain.rays == st_part.rays
+    assert np.array_equal(plain.download()[rows].view(np.uint64), part.download()[rows].view(np.uint64))
+
+
 def test_progressive_state_is_saved_and_resumed():
     """randState is written back (R/kernel.cu:146): 2 spp then 2 more spp continues the same streams."""
     s = rt.builtin_scene(10, 0, 32, 16)

@@ -533,9 +533,10 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
     // N = 2 / 3 / 4 / 6 / 8 / 16 without classes -- no scaling at all, every rank waits for its longest chains -- and
     // 737 / 566 / 447 / 395 / 368 / 302 ms with them (profiles/r03_c5_roles.txt; the 8-way figure 293 with the settings of the
     // second sweep there: ten of twelve waves serving 32 pixels each from 8 rays per sample -- most of the frame, in half-filled waves).  A whole frame (13 generations) is throughput
-    // and loses by them (1030 -> 1400 ms and worse), as it did in r2 with other settings; so: up to five generations.
+    // and loses by them (1030 -> 1400 ms and worse), as it did in r2 with other settings; so: up to seven generations (a 2-way
+    // split, 672 -> 626 ms), in three bands of settings.
     const double generations = (double)f.n_pixels / ((double)f.num_cus * 12.0 * 64.0);
-    const bool deep_roles = deep_kernel && tune("RTOW_ROLES_DEEP", generations <= 5.0 ? 1 : 0, 0, 1) != 0;
+    const bool deep_roles = deep_kernel && tune("RTOW_ROLES_DEEP", generations <= 7.0 ? 1 : 0, 0, 1) != 0;
     const bool ppw_given = (p->pixels_per_wave > 0 && p->pixels_per_wave < 64) || tune_set("RTOW_PIXELS_PER_WAVE");
     bool split = (sphere_list_kernel || prim_bvh_kernel || deep_roles) && !(p->flags & RT_FLAG_NO_PIXEL_CLASSES) && p->samples_per_pixel >= 64 &&
                  f.n_pixels >= 65536u && !ppw_given;
@@ -626,8 +627,8 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             // thresholds there helped three ranks of eight (profiles/r03_rank_serving_sweep.txt) and cost the rank with the longest
             // chains a third (C2 96 -> 141 ms, C3 115 -> 148): the thresholds stay, the serving waves take fewer pixels each.
             const bool underfilled = roles_in_one_launch && (size_t)f.n_pixels <= (size_t)f.num_cus * 12u * 64u;
-            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", deep_roles ? (generations <= 2.2 ? 8 : 20) : ((sphere_list_kernel && !roles_in_one_launch) ? 12 : 9), 1, 1 << 20);
-            int heavy_ppw = tune("RTOW_HEAVY_PPW", deep_roles ? (generations <= 2.2 ? 32 : 12) : (sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6), 1, 64);
+            const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", deep_roles ? (generations <= 2.2 ? 8 : (generations <= 5.0 ? 12 : 16)) : ((sphere_list_kernel && !roles_in_one_launch) ? 12 : 9), 1, 1 << 20);
+            int heavy_ppw = tune("RTOW_HEAVY_PPW", deep_roles ? 32 : (sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6), 1, 64);
             const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
             // the serving waves' rays are the frame's critical path
             const int heavy_prio = tune("RTOW_HEAVY_PRIO", (sphere_list_kernel && roles_in_one_launch) ? 3 : 0, 0, 3);
@@ -654,7 +655,7 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
                 ra.heavy_list = f.heavy_list;
                 ra.heavy_count = f.heavy_count;
                 ra.heavy_cursor = reinterpret_cast<uint32_t *>(f.ray_counter + 6);
-                ra.heavy_waves = tune("RTOW_HEAVY_WAVES", deep_roles ? (generations <= 2.2 ? 10 : 4) : (sphere_list_kernel ? 2 : 3), 0, 12);
+                ra.heavy_waves = tune("RTOW_HEAVY_WAVES", deep_roles ? (generations <= 2.2 ? 10 : (generations <= 5.0 ? 6 : 4)) : (sphere_list_kernel ? 2 : 3), 0, 12);
                 ra.heavy_ppw = heavy_ppw;
                 ra.heavy_priority = heavy_prio;
                 // fewer pixels per serving wave than the tuned numbers only where the frame leaves lanes idle anyway -- fewer pixels

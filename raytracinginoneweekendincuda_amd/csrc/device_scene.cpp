@@ -614,18 +614,22 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
         }
         HIP_TRY(hipMemsetAsync(f.ray_counter, 0, 2 * sizeof(unsigned long long), stream));  // rays, (light) queue cursor
         if (split) {
-            // (r3) sphere lists: 12 rays per sample and four pixels per serving wave.  With eight the frame time was bimodal -- six
-            // frames in one call: 188...246 ms, mean 209 -- because the serving wave that happens to hold the longest chains sets
-            // it; with four (16 lanes per ray) the mean is 188.5 ms and the spread 186...192.  Earlier sweeps took the best of two
-            // runs per setting and did not see it (profiles/r03_c2_serving_sweep.txt).
-            // primitive BVH worlds (r3): 9 rays per sample, three serving waves per workgroup, and the longest chains of all -- 30 rays
-            // per sample and more -- one to a wave (super_list below).  Every light pixel just under the threshold runs at a light
-            // wave's 30 us per ray from the first millisecond to the frame's last (per-pixel stamps, RTOW_PRINT_TAIL), so the
-            // threshold, the serving capacity and the longest heavy chain have to be moved together: C3 162 -> 153 ms, means of
-            // four frames per setting in one call (profiles/r03_c3_serving_sweep.txt).
-            // a frame with fewer pixels than the GPU has lanes (a rank's stripes of a split frame) has serving waves to spare.  Lower
-            // thresholds there helped three ranks of eight (profiles/r03_rank_serving_sweep.txt) and cost the rank with the longest
-            // chains a third (C2 96 -> 141 ms, C3 115 -> 148): the thresholds stay, the serving waves take fewer pixels each.
+            // Serving settings (r3; every number below is the mean of several frames per setting in one gpurun call -- earlier sweeps
+            // took the best of two runs and missed a bimodal default; profiles/r03_c2_serving_sweep.txt, r03_c3_serving_sweep.txt,
+            // r03_rank_serving_sweep.txt, r03_c5_roles.txt).  What per-pixel stamps (RT_STAMP builds, RTOW_PRINT_TAIL) showed: a light
+            // pixel just under the threshold runs at a light wave's 30-40 us per ray from the frame's first millisecond to its last,
+            // a listed pixel at 7-10 us -- threshold, serving capacity and the longest listed chain have to be moved together.
+            //   sphere lists (C2)      two tiers: from 12 rays per sample four pixels to a serving wave (16 lanes per ray), from 9 eight;
+            //                          two serving waves of four per workgroup.  Eight to a wave for all: 188...246 ms by which wave
+            //                          held the longest chains; one tier of four: 198.6 ms; two tiers: 190.5
+            //   primitive BVH (C3)     from 9 rays per sample six to a serving wave, three serving waves of twelve, eight rehearsed
+            //                          samples; from 30 rays per sample ONE to a wave (super_list): 162 -> 153 ms
+            //   deep segmented (C5)    only for frames of at most seven generations of pixels per lane (deep_roles above), 32 to a
+            //                          serving wave: 8 / 12 / 16 rays per sample and 10 / 6 / 4 serving waves of twelve for up to
+            //                          2.2 / 5 / 7 generations
+            // A frame with fewer pixels than the GPU has lanes (a rank's stripes) keeps these thresholds -- lower ones helped three
+            // ranks of eight and cost the rank with the longest chains a third -- and lets its serving waves take fewer pixels each
+            // (adaptive_ppw below).
             const bool underfilled = roles_in_one_launch && (size_t)f.n_pixels <= (size_t)f.num_cus * 12u * 64u;
             const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", deep_roles ? (generations <= 2.2 ? 8 : (generations <= 5.0 ? 12 : 16)) : ((sphere_list_kernel && !roles_in_one_launch) ? 12 : 9), 1, 1 << 20);
             int heavy_ppw = tune("RTOW_HEAVY_PPW", deep_roles ? 32 : (sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6), 1, 64);
@@ -633,10 +637,6 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             // the serving waves' rays are the frame's critical path
             const int heavy_prio = tune("RTOW_HEAVY_PRIO", (sphere_list_kernel && roles_in_one_launch) ? 3 : 0, 0, 3);
             HIP_TRY(hipMemsetAsync(f.heavy_count, 0, 64, stream));
-            // the longest chains of all get a serving wave each (RenderArgs::super_list): BVH worlds, whose serving waves walk one lane per ray
-            // sphere lists, two tiers: from 12 rays per sample four pixels to a serving wave (16 lanes per ray), from 9 eight (8 lanes):
-            // a pixel of 10 rays per sample takes 200 ms in a light wave -- the whole frame -- and 50 ms in a serving wave
-            // (C2, five frames per setting in one call: 198.6 -> 190.5 ms; threshold 8: 194, 7: 201; profiles/r03_c2_serving_sweep.txt)
             const int super_rays = tune("RTOW_SUPER_RAYS", (roles_in_one_launch && !deep_roles) ? (sphere_list_kernel ? 12 : 30) : 0, 0, 1 << 20);
             const bool longest = roles_in_one_launch && super_rays > 0;
             if (longest && !f.super_list) HIP_TRY(hipMalloc((void **)&f.super_list, (size_t)f.n_pixels * sizeof(uint32_t)));

@@ -627,10 +627,10 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             //   deep segmented (C5)    only for frames of at most seven generations of pixels per lane (deep_roles above), 32 to a
             //                          serving wave: 8 / 12 / 16 rays per sample and 10 / 6 / 4 serving waves of twelve for up to
             //                          2.2 / 5 / 7 generations
-            // A frame with fewer pixels than the GPU has lanes (a rank's stripes) keeps these thresholds -- lower ones helped three
+            // A frame of few generations of pixels per lane (a rank's stripes) keeps these thresholds -- lower ones helped three
             // ranks of eight and cost the rank with the longest chains a third -- and lets its serving waves take fewer pixels each
             // (adaptive_ppw below).
-            const bool underfilled = roles_in_one_launch && (size_t)f.n_pixels <= (size_t)f.num_cus * 12u * 64u;
+            const bool few_generations = roles_in_one_launch && generations <= 3.0;  // of pixels per resident lane (twelve waves per CU)
             const int heavy_rays_per_sample = tune("RTOW_HEAVY_RAYS", deep_roles ? (generations <= 2.2 ? 8 : (generations <= 5.0 ? 12 : 16)) : ((sphere_list_kernel && !roles_in_one_launch) ? 12 : 9), 1, 1 << 20);
             int heavy_ppw = tune("RTOW_HEAVY_PPW", deep_roles ? 32 : (sphere_list_kernel ? (roles_in_one_launch ? 8 : 4) : 6), 1, 64);
             const int heavy_blocks = tune("RTOW_HEAVY_BLOCKS", sphere_list_kernel ? f.num_cus / 2 : f.num_cus, 1, 1 << 20);
@@ -658,11 +658,12 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
                 ra.heavy_waves = tune("RTOW_HEAVY_WAVES", deep_roles ? (generations <= 2.2 ? 10 : (generations <= 5.0 ? 6 : 4)) : (sphere_list_kernel ? 2 : 3), 0, 12);
                 ra.heavy_ppw = heavy_ppw;
                 ra.heavy_priority = heavy_prio;
-                // fewer pixels per serving wave than the tuned numbers only where the frame leaves lanes idle anyway -- fewer pixels
-                // than the twelve waves per CU of these kernels hold, i.e. a rank's stripes of a split frame: there a chain is
-                // shortest with its wave to itself (C2 / 8: slowest rank 135 -> 97 ms, C3 / 8: 155 -> 122).  A full frame packs the
-                // serving waves as densely as tuned: the ones left over join the light queue at once (C3 152 against 159 ms).
-                ra.adaptive_ppw = tune("RTOW_ADAPTIVE_PPW", underfilled ? 1 : 0, 0, 1);
+                // fewer pixels per serving wave than the tuned numbers where the light pixels are few -- up to three generations of
+                // pixels per lane, i.e. a rank's stripes of a split frame: the light side is short there and a listed chain is
+                // shortest with its wave to itself (slowest rank, C2 / 4: 132 -> 119 ms, / 8: 135 -> 97; C3 / 2: 153 -> 135, / 4:
+                // 154 -> 124, / 8: 155 -> 122).  A full frame packs the serving waves as densely as tuned: the ones left over join
+                // the light queue at once (C3, 4.9 generations: 152 against 159 ms).
+                ra.adaptive_ppw = tune("RTOW_ADAPTIVE_PPW", few_generations ? 1 : 0, 0, 1);
                 ra.pix_class = f.pix_class;
             } else {
                 HIP_TRY(hipEventRecord(f.ev_aux[0], stream));

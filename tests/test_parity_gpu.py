@@ -147,6 +147,24 @@ def test_final_scene_rank_stripes_with_pixel_classes_equal_the_full_frames_rows(
     assert np.array_equal(plain.download()[rows].view(np.uint64), part.download()[rows].view(np.uint64))
 
 
+@pytest.mark.parametrize("scene_id,world_kind", [(11, 1), (0, 0), (9, 0)])
+@pytest.mark.parametrize("w,h", [(1024, 512), (640, 416), (1992, 1000)])
+def test_pixel_classes_on_other_frame_sizes(earth, scene_id, world_kind, w, h):
+    """Heavy / light pixel classes (sphere lists in two tiers, the primitive BVH's one-to-a-wave list, the deep kernel's classes for
+    frames of few generations, fewer pixels per serving wave where light pixels are few) at frame sizes that land in different
+    bands of the launcher's rules: the frame, the ray count and the saved RNG streams equal those without classes."""
+    s = rt.builtin_scene(scene_id, world_kind, w, h, earth=earth if scene_id == 9 else None)
+    a, b = rt.Film(w, h), rt.Film(w, h)
+    st_a = a.render(s, 64, variant=0)
+    st_b = b.render(s, 64, variant=0, flags=64)   # RT_FLAG_NO_PIXEL_CLASSES
+    assert st_a.rays == st_b.rays
+    assert np.array_equal(a.download().view(np.uint64), b.download().view(np.uint64))
+    st_a = a.render(s, 4, variant=0, flags=1)     # RT_FLAG_KEEP_RNG_STATE: four more samples from the saved streams
+    st_b = b.render(s, 4, variant=0, flags=1 | 64)
+    assert st_a.rays == st_b.rays
+    assert np.array_equal(a.download().view(np.uint64), b.download().view(np.uint64))
+
+
 def test_progressive_state_is_saved_and_resumed():
     """randState is written back (R/kernel.cu:146): 2 spp then 2 more spp continues the same streams."""
     s = rt.builtin_scene(10, 0, 32, 16)

@@ -192,10 +192,12 @@ typedef struct rt_render_params {
 #define RT_FLAG_FORCE_GENERAL 2u   /* tests: run the general kernel even where a specialised instantiation applies */
 #define RT_FLAG_ALWAYS_WALK 32u     /* small BVH worlds without media (up to 16 cheap leaves) are rendered by scanning all leaves in the tree's
                                       leaf order (same closest hit, no node visits); this flag walks the tree anyway */
-#define RT_FLAG_NO_PIXEL_CLASSES 64u /* sphere-list and primitive-BVH worlds: hand every pixel out through the one tile queue (default: a
-                                      rehearsal of the first samples finds the few pixels with long ray chains; two waves of every workgroup
-                                      serve that list first, a few pixels at a time -- several lanes per ray in list worlds -- and the
-                                      tile queue skips them; the image is the same either way) */
+#define RT_FLAG_NO_PIXEL_CLASSES 64u /* hand every pixel out through the one tile queue (default: a rehearsal of the first samples lists the
+                                      pixels with long ray chains, and some waves of every workgroup serve those first, a few pixels per
+                                      wave, before they join the tile queue, which skips them -- sphere lists in two tiers of 4 and 8
+                                      pixels per wave with the lanes sharing each ray's scan, primitive BVH worlds on the library's tree
+                                      with the very longest chains one to a wave, deep composite worlds only where the frame is a few
+                                      generations of pixels on the GPU's lanes, e.g. one rank's stripes; the image is the same either way) */
 #define RT_FLAG_REFERENCE_TREE 128u  /* BVH worlds of primitives only are walked through the library's own tree (surface-area heuristic, near
                                       child first) -- no leaf draws random numbers there, so the closest hit is the one the reference's tree
                                       gives; this flag walks the reference's own tree in its own order instead (tests, timing).  A world in

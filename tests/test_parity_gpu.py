@@ -573,6 +573,12 @@ def test_c5_rows_at_its_real_5000_spp(oracle, earth):
     print(f"c5 x{spp}spp strict, rows {stripe * 8}..{stripe * 8 + n_rows - 1}: bit-exact {exact:.4f}, within {TOL:g}: {within:.4f}, "
           f"max |d| {worst:.3g}, {st.rays / st.samples:.2f} rays/sample")
     assert within >= 0.9995 and exact >= 0.98, (exact, within, worst)
+    # the same two rows as rank 4 of an 8-way split renders them -- 200 rows, 1.6 generations of pixels on the GPU's lanes, so
+    # with heavy and light pixel classes (device_scene.cpp deep_roles): the stripe render's pixels bit for bit
+    part = rt.Film(w, h, stripe_rows=8, rank=stripe % 8, world_size=8)
+    part.render(scene, spp, variant=0)
+    rows = part.download()[stripe * 8:stripe * 8 + n_rows]
+    assert np.array_equal(rows.view(np.uint64), got[:n_rows].view(np.uint64))
 
 
 # ---- a scene that changes between renders (frame sequences) ----

@@ -641,7 +641,12 @@ static int enqueue_frame(SceneImpl &s, FilmImpl &f, const rt_render_params *p, h
             const bool longest = roles_in_one_launch && super_rays > 0;
             if (longest && !f.super_list) HIP_TRY(hipMalloc((void **)&f.super_list, (size_t)f.n_pixels * sizeof(uint32_t)));
             HIP_TRY(launch_classify_pixels(f.pix_cost, f.n_pixels, (uint32_t)(heavy_rays_per_sample * probe_spp), f.pix_class,
-                                           f.heavy_list, f.heavy_count, stream, longest ? f.super_list : nullptr, (uint32_t)(super_rays * probe_spp)));
+                                           f.heavy_list, f.heavy_count, stream, longest ? f.super_list : nullptr, (uint32_t)(super_rays * probe_spp),
+                                           (uint32_t)f.width, (uint32_t)tune("RTOW_NEAR_PERCENT", prim_bvh_kernel ? 70 : 0, 0, 100),
+                                           (uint32_t)tune("RTOW_NEAR_NEIGHBOURS", prim_bvh_kernel ? 3 : 0, 0, 8)));
+            // (primitive BVH worlds: a pixel probed at 70 % of the threshold with three of its eight neighbours over it is listed too --
+            // the last pixel of a C3 frame was a light one probed at 8.75 rays per sample in a patch of heavy ones, really costing 16:
+            // 152.5 -> 147.8 ms, six frames per setting; sphere lists: no difference, left off)
             if (longest) {
                 HIP_TRY(hipMemsetAsync(f.ray_counter + 9, 0, sizeof(unsigned long long), stream));
                 ra.super_list = f.super_list;

@@ -3517,11 +3517,25 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *cost, 
 }
 
 __global__ __launch_bounds__(256) void classify_pixels_kernel(const uint32_t *cost, uint32_t n, uint32_t threshold, uint8_t *klass,
-                                                               uint32_t *list, uint32_t *count, uint32_t *super_list, uint32_t super_threshold)
+                                                               uint32_t *list, uint32_t *count, uint32_t *super_list, uint32_t super_threshold,
+                                                               uint32_t width, uint32_t near_percent, uint32_t near_neighbours)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const bool heavy = cost[k] >= threshold;
+    bool heavy = cost[k] >= threshold;
+    // The rehearsal is a handful of samples of a heavy-tailed count: a pixel a little under the threshold whose neighbours are over
+    // it is more likely a long chain that looked short than a short one (long chains come in patches -- a glass sphere) and goes on
+    // the list with them.  A pixel wrongly left with the light ones runs at their pace to the frame's very end.
+    if (!heavy && near_neighbours > 0 && width > 0 && cost[k] * 100u >= threshold * near_percent) {
+        const uint32_t row = k / width, column = k % width, rows = n / width;
+        uint32_t over = 0;
+        for (int dr = -1; dr <= 1; dr++)
+            for (int dc = -1; dc <= 1; dc++) {
+                const int r = (int)row + dr, c = (int)column + dc;
+                if ((dr || dc) && r >= 0 && c >= 0 && r < (int)rows && c < (int)width) over += cost[(uint32_t)r * width + (uint32_t)c] >= threshold ? 1u : 0u;
+            }
+        heavy = over >= near_neighbours;
+    }
     const bool longest = heavy && super_list && cost[k] >= super_threshold;
     klass[k] = heavy ? 1 : 0;
     if (longest) super_list[atomicAdd(count + 1, 1u)] = k;
@@ -3529,11 +3543,12 @@ __global__ __launch_bounds__(256) void classify_pixels_kernel(const uint32_t *co
 }
 
 hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, uint32_t threshold, uint8_t *pix_class, uint32_t *list,
-                                  uint32_t *count, hipStream_t stream, uint32_t *super_list, uint32_t super_threshold)
+                                  uint32_t *count, hipStream_t stream, uint32_t *super_list, uint32_t super_threshold, uint32_t width,
+                                  uint32_t near_percent, uint32_t near_neighbours)
 {
     if (n_pixels == 0) return hipSuccess;
     hipLaunchKernelGGL(classify_pixels_kernel, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, pix_cost, n_pixels, threshold,
-                       pix_class, list, count, super_list, super_threshold);
+                       pix_class, list, count, super_list, super_threshold, width, near_percent, near_neighbours);
     return hipGetLastError();
 }
 

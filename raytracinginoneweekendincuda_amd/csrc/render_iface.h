@@ -101,7 +101,8 @@ hipError_t kernel_info_fast(const DeviceScene &sc, const RenderArgs &a, KernelIn
 // least `threshold` rays, class 0 for the others; with super_list: the pixels of at least super_threshold rays go there instead
 // (length count[1])
 hipError_t launch_classify_pixels(const uint32_t *pix_cost, uint32_t n_pixels, uint32_t threshold, uint8_t *pix_class, uint32_t *list,
-                                  uint32_t *count, hipStream_t stream, uint32_t *super_list = nullptr, uint32_t super_threshold = 0);
+                                  uint32_t *count, hipStream_t stream, uint32_t *super_list = nullptr, uint32_t super_threshold = 0,
+                                  uint32_t width = 0, uint32_t near_percent = 0, uint32_t near_neighbours = 0);  // a pixel of near_percent % of the threshold with that many of its 8 neighbours over it is listed too
 
 // tile_order[k] = the tile with the k-th highest cost (counting sort over 256 cost classes; one workgroup)
 // (flat_x8 / 8 = ratio of the heaviest tile to the mean below which the row-major order is kept)

@@ -72,6 +72,8 @@ struct Traits {
     // walked once per run of leaves between two media; kind-batched leaf phases, one 768-thread workgroup per CU
     static constexpr bool SEG = FAST_ && COMPOSITE_ && BATCH_ && WORLD_ == 0 && BLOCK_ >= RT_BIG_BLOCK;
     static constexpr bool FAST = FAST_ && !COMPOSITE_ && WORLD_ == 0;
+    // kernels that can be launched with heavy / light pixel classes (RenderArgs::heavy_list): for the others the serving code folds away
+    static constexpr bool ROLES = WORLD_ == 2 || (FAST_ && WORLD_ == 0 && BLOCK_ >= RT_BIG_BLOCK) || (COMPOSITE_ && BATCH_ && WORLD_ == 0 && BLOCK_ >= RT_BIG_BLOCK);
     static constexpr int BLOCK = BLOCK_;
     static constexpr bool NESTED = NESTED_ && COMPOSITE_;
     static constexpr bool BATCH = BATCH_ && COMPOSITE_ && WORLD_ == 0;
@@ -2947,7 +2949,7 @@ __global__ __launch_bounds__(T::BLOCK, T::MIN_WAVES) void render_kernel(DeviceSc
     const CameraRec *__restrict__ cam = sc.camera;
 
     // this wave's role (wave-uniform): serve the list of heavy pixels first, a few at a time (RenderArgs::heavy_list)
-    bool heavy_mode = a.heavy_list != nullptr && (int)(threadIdx.x >> 6) < a.heavy_waves;
+    bool heavy_mode = T::ROLES && a.heavy_list != nullptr && (int)(threadIdx.x >> 6) < a.heavy_waves;
     bool heavy_dry = false;
     const uint32_t heavy_total = heavy_mode ? *(const RT_CONST uint32_t *)(uintptr_t)a.heavy_count : 0u;
     const uint32_t super_total = (heavy_mode && a.super_list) ? *(const RT_CONST uint32_t *)(uintptr_t)a.super_count : 0u;
@@ -3665,6 +3667,7 @@ hipError_t launch_one(const DeviceScene &sc_in, RenderArgs a, hipStream_t stream
 {
     DeviceScene sc = sc_in;
     [[maybe_unused]] const RenderArgs a_in = a;
+    if (!T::ROLES && a.heavy_list) return hipErrorInvalidValue;  // this instantiation has no serving waves (Traits::ROLES): its listed pixels would never be rendered
     auto kernel = render_kernel<RT_STRICT, T>;
     uint32_t tiles = (((uint32_t)a.width + 7u) >> 3) * (((uint32_t)a.rows_owned + 7u) >> 3);
     size_t lds = 0;
